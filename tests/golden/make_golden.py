@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU
+box).  The reference's Python files are imported *by path* and executed unmodified; the
+three packages they import that are not installed here (`gym`, `ray`, `cma`) are replaced
+by in-memory stand-ins that carry no arithmetic:
+
+  * gym.Env            -> empty base class (the env only subclasses it)
+  * gym.spaces.Box     -> records low/high/shape (bounds are declarative in the reference,
+                          remy_swimmer_env.py:36-39; never enforced)
+  * ray.remote         -> identity decorator (Ray is process placement only,
+                          ars/ars_agent.py:15)
+  * cma                -> empty module (only used by Estimator.estimate_real_env_param)
+
+What is written are DATA fixtures only (inputs and the reference's outputs) as .npz files
+loadable with numpy.load(allow_pickle=False).  No reference source text is stored.
+
+Usage:  python tests/golden/make_golden.py            (rewrites tests/golden/*.npz)
+"""
+import importlib.util
+import io
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+def _install_standins():
+    gym = types.ModuleType("gym")
+
+    class Env(object):
+        def close(self):
+            return None
+
+    class Box(object):
+        def __init__(self, low, high, shape=None, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Box = Box
+    gym.Env = Env
+    gym.spaces = spaces
+    sys.modules["gym"] = gym
+    sys.modules["gym.spaces"] = spaces
+
+    ray = types.ModuleType("ray")
+    ray.remote = lambda obj: obj
+    sys.modules["ray"] = ray
+    sys.modules["cma"] = types.ModuleType("cma")
+
+    # the env module, loaded by path and aliased where ars/environment.py:6 expects it
+    path = os.path.join(REF, "envs/gym_swimmer/swimmer/remy_swimmer_env.py")
+    spec = importlib.util.spec_from_file_location("remy_swimmer_env", path)
+    envmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(envmod)
+    for name in ("gym.envs", "gym.envs.swimmer"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["gym.envs.swimmer.remy_swimmer_env"] = envmod
+    sys.path.insert(0, REF)
+    return envmod
+
+
+envmod = _install_standins()
+SwimmerEnv = envmod.SwimmerEnv
+from ars.environment import Environment  # noqa: E402  (reference module)
+from ars.ars_agent import ARSAgent  # noqa: E402
+from ars.parameters import EnvParam, ARSParam  # noqa: E402
+
+PARAM_SETS = {
+    # name: (l_i, m_i, k, h)
+    "default": (1.0, 1.0, 10.0, 1e-3),          # remy_swimmer_env.py:16-17
+    "realworld": (0.8, 1.2, 10.2, 1e-3),        # ars/plot_graph.py:14-16
+    "odd": (1.3, 0.7, 4.5, 2.5e-3),             # non-default everything (pivoting differs)
+}
+
+
+def make_env(n, pset, direction=(1.0, 0.0)):
+    l_i, m_i, k, h = PARAM_SETS[pset]
+    return SwimmerEnv(direction=list(direction), n=n, l_i=l_i, m_i=m_i, k=k, h=h)
+
+
+def gen_steps():
+    """Single-step vectors: random states/actions (SURVEY §8d C2 distributions)."""
+    out = {}
+    rng = np.random.default_rng(0)
+    for n in (2, 3, 4, 5, 6, 8):
+        for pset in PARAM_SETS:
+            B = 48
+            d, m = 2 * n + 2, n - 1
+            states = np.empty((B, d))
+            states[:, 0:2] = rng.uniform(-0.5, 0.5, (B, 2))
+            states[:, 2::2] = rng.uniform(-np.pi, np.pi, (B, n))
+            states[:, 3::2] = rng.uniform(-2, 2, (B, n))
+            actions = rng.uniform(-5, 5, (B, m))
+            direction = (1.0, 0.0) if pset != "odd" else (0.6, -0.8)
+            env = make_env(n, pset, direction)
+            nxt = np.empty((B, d))
+            rew = np.empty(B)
+            gdd = np.empty((B, 2))
+            tdd = np.empty((B, n))
+            for b in range(B):
+                env.set_state(states[b].tolist())
+                g, t = env.compute_accelerations(actions[b], env.G_dot, env.theta, env.theta_dot)
+                gdd[b], tdd[b] = g, t
+                ob, r, done, info = env.step(actions[b])
+                assert done is False and info == {}
+                nxt[b], rew[b] = ob, r
+            key = f"n{n}_{pset}"
+            out[key + "_state"] = states
+            out[key + "_action"] = actions
+            out[key + "_next"] = nxt
+            out[key + "_reward"] = rew
+            out[key + "_gdd"] = gdd
+            out[key + "_tdd"] = tdd
+            out[key + "_dir"] = np.array(direction)
+    np.savez_compressed(os.path.join(OUT, "steps.npz"), **out)
+    print("steps.npz", len(out))
+
+
+def gen_kat():
+    """Known-answer state from rlglue/test/acceleration-compare.txt:5 evaluated by the Gym env,
+    plus reset / first-step anchors."""
+    out = {}
+    kat = [-0.0453422, 1.33766e-11, -1.35003, -1.4868, 1.5708, -1.88179e-15, -1.79156, 1.4868]
+    env = make_env(3, "default")
+    out["reset"] = np.array(env.reset())
+    ob, r, _, _ = env.step([2.5, 2.5])
+    out["reset_step_u25"] = np.array(ob)
+    out["reset_step_u25_reward"] = np.array(r)
+    out["kat_state"] = np.array(kat)
+    for tag, u in (("u0", [0.0, 0.0]), ("u25", [2.5, 2.5]), ("u5m5", [5.0, -5.0])):
+        env.set_state(kat)
+        g, t = env.compute_accelerations(np.array(u), env.G_dot, env.theta, env.theta_dot)
+        out[f"kat_{tag}_u"] = np.array(u)
+        out[f"kat_{tag}_gdd"] = np.array(g)
+        out[f"kat_{tag}_tdd"] = np.array(t)
+    # Coulom's own recorded barycentre acceleration for that state (acceleration-compare.txt:6)
+    out["coulom_gdd_printed"] = np.array([0.284343, -8.38483e-11])
+    np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
+    print("kat.npz")
+
+
+def gen_trajectories():
+    """1000-step trajectories through the reference Environment.rollout (V1 and V2 action paths)
+    and the env module's own __main__ scenario (remy_swimmer_env.py:301-316)."""
+    out = {}
+    # (1) module __main__ scenario: seed 23 random state, zero policy, 1000 steps
+    np.random.seed(23)
+    env = make_env(3, "default")
+    env.reset()
+    env.G_dot = np.random.rand(2)
+    env.theta = np.random.rand(3)
+    env.theta_dot = np.random.rand(3)
+    s0 = np.array(env.get_state())
+    traj = np.empty((1000, 8))
+    rews = np.empty(1000)
+    for t in range(1000):
+        ob, r, _, _ = env.step(np.zeros(2))
+        traj[t], rews[t] = ob, r
+    out["main23_state0"] = s0
+    out["main23_traj"] = traj
+    out["main23_rewards"] = rews
+    out["main23_total"] = np.array(np.sum(rews))
+    tot = 0.0
+    for r in rews:
+        tot += r
+    out["main23_total_seq"] = np.array(tot)
+
+    # (2) rollouts from reset through ars/environment.py (V1 path: covariance=None)
+    for n, pset, scale, H in ((3, "default", 0.0, 1000), (3, "default", 0.1, 1000),
+                              (3, "realworld", 0.1, 1000), (6, "default", 0.1, 1000),
+                              (5, "realworld", 0.05, 400), (3, "default", 1.0, 1000),
+                              (6, "odd", 0.3, 300)):
+        l_i, m_i, k, h = PARAM_SETS[pset]
+        ep = EnvParam("LeonSwimmer-Golden", n=n, H=H, l_i=l_i, m_i=m_i, h=h, k=k, epsilon=0)
+        renv = Environment(ep)
+        d, m = 2 * n + 2, n - 1
+        P = scale * (2 * np.random.RandomState(0).rand(m, d) - 1)
+        ret, states = renv.rollout(P)
+        key = f"roll_n{n}_{pset}_s{scale}_H{H}"
+        out[key + "_policy"] = P
+        out[key + "_return"] = np.array(ret)
+        out[key + "_traj"] = np.array(states)
+
+    # (3) V2 action path: whitening with a given mean / covariance (ars/environment.py:31-34)
+    for n, pset, H in ((3, "default", 1000), (6, "realworld", 500)):
+        l_i, m_i, k, h = PARAM_SETS[pset]
+        ep = EnvParam("LeonSwimmer-Golden", n=n, H=H, l_i=l_i, m_i=m_i, h=h, k=k, epsilon=0)
+        renv = Environment(ep)
+        d, m = 2 * n + 2, n - 1
+        rs = np.random.RandomState(7)
+        P = 0.05 * (2 * rs.rand(m, d) - 1)
+        mean = 0.1 * rs.randn(d)
+        mean[2::2] += np.pi / 2
+        A = rs.randn(d, d)
+        cov = 0.05 * A @ A.T + np.diag(rs.uniform(0.2, 2.0, d))
+        ret, states = renv.rollout(P, covariance=cov, mean=mean)
+        key = f"rollv2_n{n}_{pset}_H{H}"
+        out[key + "_policy"] = P
+        out[key + "_mean"] = mean
+        out[key + "_cov"] = cov
+        out[key + "_return"] = np.array(ret)
+        out[key + "_traj"] = np.array(states)
+    np.savez_compressed(os.path.join(OUT, "trajectories.npz"), **out)
+    print("trajectories.npz", len(out))
+
+
+def gen_ars():
+    """ARS iterations through the reference ARSAgent (ars/ars_agent.py:132-185)."""
+    out = {}
+    cases = (
+        # tag, n, pset, V1, N, b, H, alpha, nu, seed, iters
+        ("v2_n3_N4_H50", 3, "default", False, 4, 4, 50, 0.0075, 0.01, 0, 3),
+        ("v2_n3_N8_H50", 3, "default", False, 8, 8, 50, 0.0075, 0.01, 0, 3),
+        ("v2_n3_N4_H1000", 3, "default", False, 4, 4, 1000, 0.0075, 0.01, 0, 3),
+        ("v2_n3_N6_H200_rw", 3, "realworld", False, 6, 3, 200, 0.0075, 0.01, 3, 4),
+        ("v1_n3_N4_H100", 3, "default", True, 4, 4, 100, 0.01, 0.02, 1, 4),
+        ("v2_n6_N4_H100", 6, "default", False, 4, 2, 100, 0.0075, 0.01, 2, 3),
+        ("v1_n3_N1_H1000", 3, "realworld", True, 1, 1, 1000, 0.0075, 0.01, 0, 5),
+    )
+    for tag, n, pset, V1, N, b, H, alpha, nu, seed, iters in cases:
+        l_i, m_i, k, h = PARAM_SETS[pset]
+        ep = EnvParam("LeonSwimmer-Golden", n=n, H=H, l_i=l_i, m_i=m_i, h=h, k=k, epsilon=0)
+        ap = ARSParam("Golden", V1=V1, n_iter=iters, H=H, N=N, b=b, alpha=alpha, nu=nu,
+                      safe=False, threshold=0, initial_w="Zero")
+        agent = ARSAgent(ep, ap, seed=seed)
+        d, m = 2 * n + 2, n - 1
+        rewards = np.empty((iters, 2 * N))
+        policies = np.empty((iters, m, d))
+        means = np.zeros((iters, d))
+        covs = np.zeros((iters, d, d))
+        for it in range(iters):
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = agent.runOneIteration()
+            rewards[it] = r
+            policies[it] = agent.policy
+            if not V1:
+                means[it] = agent.mean
+                covs[it] = agent.covariance
+        out[tag + "_cfg"] = np.array([n, int(V1), N, b, H, seed, iters], dtype=np.int64)
+        out[tag + "_phys"] = np.array([l_i, m_i, k, h, alpha, nu])
+        out[tag + "_rewards"] = rewards
+        out[tag + "_policies"] = policies
+        out[tag + "_means"] = means
+        out[tag + "_covs"] = covs
+        out[tag + "_nstates"] = np.array(len(agent.saved_states), dtype=np.int64)
+        # trajectory store as the reference keeps it (ars/database.py:31-34): first / last entries
+        out[tag + "_db_size"] = np.array(agent.database.size, dtype=np.int64)
+        out[tag + "_db_first_policy"] = np.array(agent.database.policies[0])
+        out[tag + "_db_first_traj_head"] = np.array(agent.database.trajectories[0][:5])
+        out[tag + "_db_last_traj_tail"] = np.array(agent.database.trajectories[-1][-5:])
+
+    # runTraining curve (ars_agent.py:187-220): 1 warm-up + n_iter iterations, mean of 2N returns
+    ep = EnvParam("LeonSwimmer-Golden", n=3, H=60, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = ARSParam("Golden", V1=False, n_iter=4, H=60, N=3, b=3, alpha=0.0075, nu=0.01,
+                  safe=False, threshold=0, initial_w="Zero")
+    agent = ARSAgent(ep, ap, seed=5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        curve = agent.runTraining()
+    out["train_v2_n3_N3_H60_curve"] = np.array(curve)
+    out["train_v2_n3_N3_H60_policy"] = np.array(agent.policy)
+    np.savez_compressed(os.path.join(OUT, "ars.npz"), **out)
+    print("ars.npz", len(out))
+
+
+if __name__ == "__main__":
+    gen_kat()
+    gen_steps()
+    gen_trajectories()
+    gen_ars()
