@@ -1,0 +1,153 @@
+/*
+ * swimmer_hip.h -- C ABI of libswimmer_hip.so, the MI355X (gfx950) implementation of the
+ * reference's swimmer-physics + ARS-rollout hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers and sizes, allocates
+ * nothing, keeps no global state, never throws, and is asynchronous on the HIP stream it
+ * is given (`stream` is a hipStream_t passed as void*; NULL = the default stream).  All
+ * arithmetic is IEEE fp64.  All pointers are DEVICE pointers unless marked "host".
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   sw_step_f64          SwimmerEnv.step -> next_observation -> compute_accelerations ->
+ *                        solve, + get_reward     envs/gym_swimmer/swimmer/remy_swimmer_env.py:41-56,
+ *                                                :69-93, :95-214, :238-243
+ *   sw_accel_f64         SwimmerEnv.compute_accelerations           remy_swimmer_env.py:95-114
+ *   sw_reset_f64         SwimmerEnv.reset                           remy_swimmer_env.py:58-67
+ *   sw_rollout_f64       Environment.select_action + .rollout       ars/environment.py:19-57
+ *   sw_ars_rollouts_f64  ARSAgent.runOneIteration's perturb + 2N rollouts loop
+ *                                                                   ars/ars_agent.py:137-172
+ *   sw_ars_update_f64    ARSAgent.sort_directions / update_policy and the V2 statistics
+ *                                                                   ars/ars_agent.py:97-130, :176-182
+ *   sw_traj_moments_f64  np.mean / np.cov over the saved states     ars/ars_agent.py:180-182
+ *
+ * Layouts (d = 2n+2 observation size, m = n-1 action size):
+ *   state, SoA    [d][n_env]   field-major: row f holds field f of every env; fields are
+ *                              the reference's observation order [Gdx, Gdy, th1, thd1, ...,
+ *                              thn, thdn] (remy_swimmer_env.py:216-224).  Coalesced: lane e
+ *                              of a wave reads element e of each row.
+ *   action, SoA   [m][n_env]
+ *   policies, AoS [n_roll][m][d]   exactly numpy's np.array(list_of_(m,d)_matrices)
+ *   deltas,  AoS  [n_dir][m][d]    ars_agent.py:137-138
+ *   traj          [H][d][n_roll]   step-major, then field, then rollout (coalesced stores);
+ *                                  the reference's trajectories[r][t][f] is traj[t][f][r]
+ *   returns       [n_roll];  for the ARS entry point rollout 2i is P+nu*delta_i and 2i+1 is
+ *                            P-nu*delta_i, the reference's `rewards` order (ars_agent.py:161-169)
+ */
+#ifndef SWIMMER_HIP_H
+#define SWIMMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_ABI_VERSION 1
+#define SW_MAX_SEGMENTS 8 /* kernels are instantiated for n = 2..8 */
+
+/* status codes (return values) */
+#define SW_OK 0
+#define SW_ERR_NULL 1        /* a required pointer is NULL */
+#define SW_ERR_SEGMENTS 2    /* n outside 2..SW_MAX_SEGMENTS */
+#define SW_ERR_SIZE 3        /* negative / zero size where not allowed */
+#define SW_ERR_PARAM 4       /* non-finite or non-positive l_i / m_i, non-finite k / h */
+#define SW_ERR_LAUNCH 5      /* hipLaunch failed; see hipGetLastError on the caller side */
+
+/* per-env / per-rollout status bits written to the optional `status` arrays */
+#define SW_STATUS_OK 0
+#define SW_STATUS_SINGULAR 1 /* a pivot of the joint-acceleration system was <= 0 or not
+                                finite: numpy.linalg.solve would raise LinAlgError
+                                (remy_swimmer_env.py:212) */
+#define SW_STATUS_NONFINITE 2 /* the new state contains inf / nan */
+
+/* Physical parameters of one swimmer model: SwimmerEnv.__init__ (remy_swimmer_env.py:16-39).
+ * max_u is not here: the reference never enforces it (actions are not clipped). */
+typedef struct sw_params {
+    int32_t n;        /* segments */
+    int32_t flags;    /* reserved, must be 0 */
+    double l_i;       /* segment length */
+    double m_i;       /* segment mass */
+    double k;         /* viscous friction coefficient */
+    double h;         /* explicit-Euler time step */
+    double dir_x;     /* reward = Gdot_new . direction */
+    double dir_y;
+} sw_params;
+
+int sw_abi_version(void);
+const char *sw_strerror(int code);
+int sw_max_segments(void);
+
+/* state[f][e] <- reset state (Gdot = 0, theta = pi/2, thetadot = 0). */
+int sw_reset_f64(const sw_params *p, int64_t n_env, double *state, void *stream);
+
+/* One physics step for n_env independent swimmers.  state_out may alias state_in.
+ * reward and status may be NULL. */
+int sw_step_f64(const sw_params *p, int64_t n_env, const double *state_in,
+                const double *action, double *state_out, double *reward,
+                int32_t *status, void *stream);
+
+/* Accelerations only: gdd [2][n_env], tdd [n][n_env]. */
+int sw_accel_f64(const sw_params *p, int64_t n_env, const double *state,
+                 const double *action, double *gdd, double *tdd, void *stream);
+
+/* n_roll independent H-step rollouts of a linear policy, one policy per rollout.
+ *   mean, inv_std : [d] each, both NULL -> ARS V1 action a = P s; both given -> V2 action
+ *                   a = (P diag(inv_std)) (s - mean), inv_std = diag(cov) ** -0.5
+ *   state0        : [d][n_roll] start states, NULL -> reset state
+ *   returns       : [n_roll] sum of the H rewards
+ *   traj          : NULL or [H][d][n_roll], every post-step state
+ *   final_state   : NULL or [d][n_roll]
+ *   moments       : NULL or [sw_moments_blocks(n_roll)][2d] per-workgroup partial sums
+ *                   sum(s - c) and sum((s - c)^2) over all post-step states, c = reset state
+ *   status        : NULL or [n_roll] */
+int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *policies,
+                   const double *mean, const double *inv_std, const double *state0,
+                   double *returns, double *traj, double *final_state, double *moments,
+                   int32_t *status, void *stream);
+
+/* Number of per-workgroup partial-moment rows sw_rollout_f64 / sw_ars_rollouts_f64 write
+ * for n_roll rollouts. */
+int64_t sw_moments_blocks(int64_t n_roll);
+
+/* The ARS exploration batch: for directions i in [dir_begin, dir_begin + n_dir) run the two
+ * rollouts P + nu*delta_i and P - nu*delta_i (perturbation fused into the kernel prologue).
+ *   policy  : [m][d]          deltas : [>= dir_begin + n_dir][m][d]
+ *   returns : [2 * n_dir] local slice, entry 2j / 2j+1 = +/- rollout of direction dir_begin+j
+ *   traj    : NULL or [H][d][2 * n_dir];  moments as in sw_rollout_f64 with n_roll = 2 n_dir */
+int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, int32_t H,
+                        const double *policy, const double *deltas, double nu,
+                        const double *mean, const double *inv_std, double *returns,
+                        double *traj, double *moments, int32_t *status, void *stream);
+
+/* ARS policy update + V2 statistics.
+ *   returns       : [2 * n_dir] all returns of the iteration (after the all-gather)
+ *   policy        : [m][d], updated in place:
+ *                   P += alpha / (b * sigma_R) * sum_{i in used}(r_i+ - r_i-) delta_i
+ *                   sigma_R = population std (ddof = 0) of the used returns.
+ *   top_b         : 0 -> the reference's behaviour: every direction is used, b is only a
+ *                   divisor (ars_agent.py:176-177, :126-128);  > 0 -> only the top_b
+ *                   directions by max(r+, r-) are used (safe_ars/ars.py:95-96)
+ *   moments       : NULL (V1) or [n_moment_rows][2d] partial sums of this iteration
+ *   running       : NULL (V1) or [1 + 2d] running {count, sum(s-c), sum((s-c)^2)} over the
+ *                   whole training, updated in place (ars_agent.py:171, :180: never cleared)
+ *   n_new_states  : states added this iteration (2 * n_dir * H over all ranks)
+ *   mean, inv_std : NULL (V1) or [d] each, overwritten with the new mean and
+ *                   var ** -0.5 (var with ddof = 1, np.cov's default)
+ *   sigma_out     : NULL or [1] */
+int sw_ars_update_f64(const sw_params *p, int64_t n_dir, const double *returns,
+                      const double *deltas, double *policy, double alpha, double b,
+                      int64_t top_b, const double *moments, int64_t n_moment_rows,
+                      double *running, int64_t n_new_states, double *mean, double *inv_std,
+                      double *sigma_out, void *stream);
+
+/* Full first and second moments of recorded trajectories (for the `covariance` attribute):
+ * acc[0] += count, acc[1..d] += sum(s - c), acc[1+d + f*d + g] += sum((s-c)_f (s-c)_g),
+ * over traj [H][d][n_roll]; acc is [1 + d + d*d] and must be zeroed by the caller before
+ * the first call.  HBM-bound: reads the trajectory buffer exactly once. */
+int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
+                        double *acc, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIMMER_HIP_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of the C ABI declared in include/swimmer_hip.h.
+
+There is no CPU fallback: if csrc/libswimmer_hip.so is missing or a GPU is not present,
+every compute entry point raises.  Tensors are torch CUDA(ROCm) float64 tensors; torch is
+used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # imported before the library so that both share one libamdhip64
+
+from . import _build
+
+ABI_VERSION = 1
+MAX_SEGMENTS = 8
+
+ERR_NAMES = {0: "SW_OK", 1: "SW_ERR_NULL", 2: "SW_ERR_SEGMENTS", 3: "SW_ERR_SIZE",
+             4: "SW_ERR_PARAM", 5: "SW_ERR_LAUNCH"}
+STATUS_SINGULAR = 1
+STATUS_NONFINITE = 2
+
+
+class SwParams(ctypes.Structure):
+    """struct sw_params (include/swimmer_hip.h)."""
+    _fields_ = [("n", ctypes.c_int32), ("flags", ctypes.c_int32), ("l_i", ctypes.c_double),
+                ("m_i", ctypes.c_double), ("k", ctypes.c_double), ("h", ctypes.c_double),
+                ("dir_x", ctypes.c_double), ("dir_y", ctypes.c_double)]
+
+    @classmethod
+    def make(cls, n=3, l_i=1.0, m_i=1.0, k=10.0, h=1e-3, direction=(1.0, 0.0)):
+        return cls(int(n), 0, float(l_i), float(m_i), float(k), float(h),
+                   float(direction[0]), float(direction[1]))
+
+    @property
+    def d(self):
+        return 2 * self.n + 2
+
+    @property
+    def m(self):
+        return self.n - 1
+
+
+class SwimmerHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_PROTOTYPES = {
+    # name: (restype, argtypes)
+    "sw_abi_version": (ctypes.c_int, []),
+    "sw_max_segments": (ctypes.c_int, []),
+    "sw_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "sw_moments_blocks": (ctypes.c_int64, [ctypes.c_int64]),
+    "sw_reset_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_void_p]),
+    "sw_step_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 6),
+    "sw_accel_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5),
+    "sw_rollout_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
+                       + [ctypes.c_void_p] * 10),
+    "sw_ars_rollouts_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_double] + [ctypes.c_void_p] * 7),
+    "sw_ars_update_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
+    "sw_traj_moments_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load csrc/libswimmer_hip.so (never builds implicitly, never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise SwimmerHipError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sw_abi_version() != ABI_VERSION:
+        raise SwimmerHipError(f"ABI version mismatch: library {lib.sw_abi_version()}, "
+                              f"binding {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise SwimmerHipError("no ROCm GPU visible: the swimmer kernels run on MI355X only "
+                              "(there is no CPU fallback)")
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sw_strerror(rc).decode()
+        raise SwimmerHipError(f"{what}: {ERR_NAMES.get(rc, rc)} ({msg})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous float64 / int32 CUDA tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise SwimmerHipError("expected a contiguous tensor on the GPU")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_f64(x, device):
+    """Host data / tensor -> contiguous float64 tensor on `device`."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=device)

@@ -1,0 +1,244 @@
+"""Augmented Random Search driver: mirror of the reference `ARSAgent`
+(ars/ars_agent.py:16-220, the unsafe V1/V2 path).
+
+Same constructor arguments, same public methods (runOneIteration, runTraining,
+sort_directions, update_policy) and attributes (policy, mean, covariance, agent_param,
+database), same random stream (NumPy's global legacy generator, seeded in __init__, deltas
+drawn as 2*rand(m, d)-1, ars_agent.py:95,137).  What differs is where the work happens:
+
+  * the N perturbations and the 2N rollouts of an iteration are ONE launch of the fused
+    rollout kernel (sw_ars_rollouts_f64) on this rank's shard of the directions;
+  * returns and V2 moment rows are exchanged with ONE all-gather (RCCL) per iteration;
+  * sigma_R, the policy step and the running V2 statistics are ONE launch of
+    sw_ars_update_f64, run redundantly and deterministically on every rank;
+  * the full state covariance (only its diagonal feeds the policy, ars/environment.py:32)
+    is one HBM-bound pass over the recorded trajectories (sw_traj_moments_f64).
+
+The safe-exploration gate (ars_agent.py:144-157) is sequential by construction and is not
+part of this path: agent_param.safe=True raises NotImplementedError.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import kernels
+from .._lib import SwParams, SwimmerHipError
+from .database import Database
+from .environment import Environment
+from .sharding import exchange, shard_bounds
+
+
+class ARSAgent(object):
+
+    def __init__(self, real_env_param, agent_param, data_path=None, seed=None,
+                 guess_param=None, approx_error=None, sim_thresh=None, *, device=None,
+                 process_group=None, record_trajectories=False, full_covariance=True,
+                 top_b=0):
+        if agent_param.safe:
+            raise NotImplementedError(
+                "safe exploration (ars_agent.py:144-157) gates every real rollout on a "
+                "simulator rollout, one at a time; it is outside the data-parallel path")
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.rank = dist.get_rank(process_group) if self.distributed else 0
+        if device is None:
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+        self.device = torch.device(device)
+
+        self.real_env_param = real_env_param
+        self.real_world = Environment(real_env_param, device=device)
+        self.agent_param = agent_param
+        self.database = Database()
+        self.record_trajectories = record_trajectories
+        self.full_covariance = full_covariance and not agent_param.V1
+        self.top_b = int(top_b)
+
+        n = real_env_param.n
+        self.m, self.d = n - 1, 2 * n + 2
+        # direction / max_u keep the env defaults, as in the reference (environment.py:15-17)
+        self.params = SwParams.make(n, real_env_param.l_i, real_env_param.m_i,
+                                    real_env_param.k, real_env_param.h, (1.0, 0.0))
+        if agent_param.initial_w == 'Zero':
+            policy = np.zeros((self.m, self.d))
+        else:
+            policy = np.load(agent_param.initial_w)
+            assert policy.shape == (self.m, self.d)
+
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._policy = torch.as_tensor(np.ascontiguousarray(policy, dtype=np.float64),
+                                       device=self.device)
+        self.v2 = not agent_param.V1
+        self._mean = torch.zeros(self.d, **f64) if self.v2 else None
+        self._inv_std = torch.ones(self.d, **f64) if self.v2 else None
+        self._running = torch.zeros(1 + 2 * self.d, **f64) if self.v2 else None
+        self._cov_acc = torch.zeros(1 + self.d + self.d * self.d, **f64) \
+            if self.full_covariance else None
+        self._sigma = torch.zeros(1, **f64)
+        self.n_saved_states = 0
+
+        N, H = agent_param.N, agent_param.H
+        self.lo, self.hi, self.chunk = shard_bounds(N, self.rank, self.world)
+        self.n_local = self.hi - self.lo
+        self.rows_chunk = kernels.moments_blocks(2 * self.chunk) if self.v2 else 0
+        self._deltas = torch.empty((N, self.m, self.d), **f64)
+        self._deltas_host = [torch.empty((N, self.m, self.d), dtype=torch.float64).pin_memory()
+                             for _ in range(2)]
+        self._h2d_done = [None, None]
+        self._flip = 0
+        self._returns_local = torch.empty(2 * self.n_local, **f64)
+        self._moments_local = (torch.zeros((kernels.moments_blocks(2 * self.n_local),
+                                            2 * self.d), **f64) if self.v2 else None)
+        need_traj = self.full_covariance or record_trajectories
+        self._traj = (torch.empty((H, self.d, 2 * self.n_local), **f64)
+                      if need_traj and self.n_local > 0 else None)
+        self._status = torch.zeros(max(1, 2 * self.n_local), dtype=torch.int32,
+                                   device=self.device)
+
+        # Randomness: the reference seeds NumPy's global generator (ars_agent.py:94-95)
+        self.n_seed = seed
+        np.random.seed(self.n_seed)
+
+    # ---- attributes the reference exposes -------------------------------------------
+    @property
+    def policy(self):
+        return self._policy.cpu().numpy()
+
+    @policy.setter
+    def policy(self, value):
+        self._policy.copy_(torch.as_tensor(np.ascontiguousarray(value, dtype=np.float64)))
+
+    @property
+    def mean(self):
+        return None if not self.v2 else self._mean.cpu().numpy()
+
+    @property
+    def covariance(self):
+        """np.cov(all saved states) (ddof = 1, ars_agent.py:182).  The diagonal is the one
+        the policy whitening uses; off-diagonals need full_covariance=True."""
+        if not self.v2:
+            return None
+        if self.n_saved_states == 0:
+            return np.identity(self.d)
+        var = self._inv_std.cpu().numpy() ** -2.0
+        if not self.full_covariance:
+            return np.diag(var)
+        acc = self._cov_acc.cpu().numpy()
+        n, s1 = acc[0], acc[1:1 + self.d]
+        s2 = acc[1 + self.d:].reshape(self.d, self.d)
+        cov = (s2 - np.outer(s1, s1) / n) / (n - 1.0)
+        cov[np.diag_indices(self.d)] = var
+        return cov
+
+    # ---- pieces of an iteration -----------------------------------------------------
+    def sample_deltas(self):
+        """N perturbations, uniform on (-1, 1): the reference's exact call sequence
+        (N draws of rand(m, d) from the global generator consume the stream exactly like
+        one rand(N, m, d))."""
+        return 2 * np.random.rand(self.agent_param.N, self.m, self.d) - 1
+
+    def _upload_deltas(self, deltas):
+        i = self._flip
+        self._flip ^= 1
+        if self._h2d_done[i] is not None:
+            self._h2d_done[i].synchronize()
+        self._deltas_host[i].copy_(torch.from_numpy(np.ascontiguousarray(deltas)))
+        self._deltas.copy_(self._deltas_host[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._h2d_done[i] = ev
+
+    def sort_directions(self, deltas, rewards):
+        """Directions sorted by max(r+, r-), best first (ars_agent.py:97-108)."""
+        r = np.asarray(rewards, dtype=np.float64).reshape(-1, 2)
+        return np.argsort(r.max(axis=1)).tolist()[::-1]
+
+    def update_policy(self, deltas, rewards, order):
+        """P += alpha / (b sigma_R) sum_{i in order} (r_i+ - r_i-) delta_i
+        (ars_agent.py:110-130), on the GPU.  `order` selects the directions used."""
+        order = list(order)
+        d = kernels._lib.dev_f64(np.asarray(deltas, dtype=np.float64)[order], self.device)
+        r = np.asarray(rewards, dtype=np.float64).reshape(-1, 2)[order].reshape(-1)
+        r = kernels._lib.dev_f64(r, self.device)
+        kernels.ars_update(self.params, r, d, self._policy, self.agent_param.alpha,
+                           self.agent_param.b, 0, sigma_out=self._sigma)
+
+    def run_iteration_async(self, deltas=None):
+        """One ARS iteration; returns the [2N] returns as a device tensor without
+        synchronising the host."""
+        ap = self.agent_param
+        if deltas is None:
+            deltas = self.sample_deltas()
+        self._upload_deltas(deltas)
+        if self.n_local > 0:
+            kernels.ars_rollouts(self.params, ap.H, self._policy, self._deltas, ap.nu,
+                                 self.lo, self.n_local, mean=self._mean,
+                                 inv_std=self._inv_std, returns=self._returns_local,
+                                 traj=self._traj, moments=self._moments_local,
+                                 status=self._status)
+        returns_all, moments_all = exchange(self._returns_local, self._moments_local, ap.N,
+                                            self.world, self.group, self.rows_chunk)
+        n_new = 2 * ap.N * ap.H
+        kernels.ars_update(self.params, returns_all, self._deltas, self._policy, ap.alpha,
+                           ap.b, self.top_b, moments=moments_all, running=self._running,
+                           n_new_states=n_new, mean=self._mean, inv_std=self._inv_std,
+                           sigma_out=self._sigma)
+        if self.full_covariance:
+            if self.world == 1:
+                kernels.traj_moments(self.params, self._traj, self._cov_acc)
+            else:
+                part = torch.zeros_like(self._cov_acc)
+                if self._traj is not None:
+                    kernels.traj_moments(self.params, self._traj, part)
+                dist.all_reduce(part, group=self.group)
+                self._cov_acc += part
+        if self.v2:
+            self.n_saved_states += n_new
+        if self.record_trajectories and self._traj is not None:
+            self.database.add_device_batch(self._traj.clone(), self._rollout_policies(deltas))
+        return returns_all
+
+    def _rollout_policies(self, deltas):
+        """Host copy of the 2*n_local perturbed policies of this rank's shard, in rollout
+        order (what the reference stores next to each trajectory, ars_agent.py:172)."""
+        P = self._policy_snapshot
+        out = np.empty((2 * self.n_local, self.m, self.d))
+        nd = self.agent_param.nu * np.asarray(deltas)[self.lo:self.hi]
+        out[0::2] = P + nd
+        out[1::2] = P - nd
+        return out
+
+    def runOneIteration(self):
+        """One whole ARS iteration (ars_agent.py:132-185); returns the list of 2N returns."""
+        if self.record_trajectories:
+            self._policy_snapshot = self.policy
+        rets = self.run_iteration_async()
+        out = rets.cpu().numpy()
+        if int((self._status != 0).sum().item()):
+            raise np.linalg.LinAlgError("Singular matrix / non-finite state in a rollout")
+        return out.tolist()
+
+    def runTraining(self, save_data_path=None, save_policy_path=None):
+        """1 warm-up iteration + n_iter iterations; curve = mean of the 2N returns
+        (ars_agent.py:187-220)."""
+        rewards = [np.mean(self.runOneIteration())]
+        for j in range(1, self.agent_param.n_iter + 1):
+            all_rewards = self.runOneIteration()
+            r = np.mean(all_rewards) if len(all_rewards) > 0 else rewards[-1]
+            rewards.append(r)
+            if j % 10 == 0:
+                if self.rank == 0:
+                    print(f"Seed {self.n_seed} ------ V1 = {self.agent_param.V1}; "
+                          f"n={self.real_env_param.n}; h={self.real_env_param.h}; "
+                          f"alpha={self.agent_param.alpha}; nu={self.agent_param.nu}; "
+                          f"N={self.agent_param.N}; b={self.agent_param.b}; "
+                          f"m_i={self.real_env_param.m_i}; l_i={self.real_env_param.l_i} "
+                          f"------ Iteration {j}/{self.agent_param.n_iter}: {r}")
+                if save_data_path is not None and self.rank == 0:
+                    self.database.save(save_data_path)
+        self.real_world.close()
+        if save_policy_path is not None and self.rank == 0:
+            np.save(save_policy_path, self.policy)
+        return np.array(rewards)

@@ -1,0 +1,58 @@
+"""Sharding of the ARS direction batch over ranks (one process per GPU, RCCL over xGMI).
+
+The 2N rollouts of an iteration are independent given (policy, mean, cov)
+(ars/ars_agent.py:140-172), so rank r runs directions [r*chunk, (r+1)*chunk) and ONE
+all-gather per iteration carries both the returns and the per-workgroup V2 moment rows
+(a few KB: latency-bound, link bandwidth is irrelevant).  The gather is rank-major, which
+preserves the reference's `rewards[2i], rewards[2i+1]` indexing (ars_agent.py:105,122).
+Every rank then runs the same deterministic update, so no broadcast is needed.
+
+These helpers are device-agnostic (they only touch torch tensors and torch.distributed) so
+the world_size > 1 logic is exercised on CPU with the gloo backend in tests/.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_dir, rank, world):
+    """Directions [lo, hi) owned by `rank`; `chunk` is the (padded) per-rank slot count."""
+    chunk = -(-n_dir // world)
+    lo = min(n_dir, rank * chunk)
+    hi = min(n_dir, lo + chunk)
+    return lo, hi, chunk
+
+
+def pack_local(returns_local, moments_local, chunk, rows_chunk):
+    """[2*chunk returns | rows_chunk * w moment values], zero padded."""
+    w = 0 if moments_local is None else moments_local.shape[1]
+    buf = torch.zeros(2 * chunk + rows_chunk * w, dtype=torch.float64,
+                      device=returns_local.device)
+    buf[:returns_local.numel()] = returns_local
+    if moments_local is not None and moments_local.numel():
+        buf[2 * chunk:2 * chunk + moments_local.numel()] = moments_local.reshape(-1)
+    return buf
+
+
+def exchange(returns_local, moments_local, n_dir, world, group=None, rows_chunk=0):
+    """All-gather one iteration's results.
+
+    returns_local : [2 * n_local]        moments_local : [rows_local, w] or None
+    -> (returns_all [2 * n_dir], moments_all [world * rows_chunk, w] or None)
+    """
+    chunk = -(-n_dir // world)
+    if world == 1:
+        return returns_local, moments_local
+    w = 0 if moments_local is None else moments_local.shape[1]
+    buf = pack_local(returns_local, moments_local, chunk, rows_chunk)
+    out = torch.empty((world, buf.numel()), dtype=torch.float64, device=buf.device)
+    try:
+        dist.all_gather_into_tensor(out, buf, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        out = torch.stack(parts)
+    returns_all = out[:, :2 * chunk].reshape(-1)[:2 * n_dir].contiguous()
+    moments_all = None
+    if moments_local is not None:
+        moments_all = out[:, 2 * chunk:].reshape(world * rows_chunk, w).contiguous()
+    return returns_all, moments_all

@@ -1,0 +1,305 @@
+// swimmer_device.h -- per-swimmer fp64 device math for gfx950 (one swimmer per lane).
+//
+// What it computes is the reference's SwimmerEnv.compute_accelerations + explicit Euler
+// (envs/gym_swimmer/swimmer/remy_swimmer_env.py:69-214).  HOW it computes it is not the
+// reference's (n+2)x(n+3) affine-row build + dense LAPACK solve: the same equations are
+// reduced analytically so that a lane needs ~120 fp64 operations for n = 3 instead of ~500,
+// no dynamic indexing and no pivoting.
+//
+// Derivation (i, j, k are 1-based segment indices; s_i = sin th_i, c_i = cos th_i,
+// n_i = (-s_i, c_i), cc_ij = cos(th_i - th_j), ss_ik = sin(th_k - th_i)):
+//
+//  * Rows 0-1 of the reference system (joint force at the free tail = 0, :193-194) sum the
+//    segment force balances; the segment-centre accelerations relative to the barycentre
+//    cancel, leaving  n m Gdd = sum_j F_j n_j  with the friction magnitudes
+//    F_j = -k l (Gdot_j . n_j) (:182).  Gdd therefore decouples from thdd and the torques.
+//  * Segment-centre velocity/acceleration in the head frame are prefix sums along the chain
+//    (:128-152); subtracting their mean (:157-163) gives fixed weights
+//        vw(j,k) = [k<j] + 1/2 [k=j] - wbar_k,   wbar_k = (n - k + 1/2) / n
+//    so  Gdot_j . n_j = Gdot . n_j + l sum_k vw(j,k) thd_k cc_jk  =: g_j.
+//  * Row 1+i (:196-205) is  (l/2) n_i . (f_i + f_{i-1}) - (m l^2/12) thdd_i
+//    + k thd_i l^3/12 + u_{i-1} - u_i = 0.  With f_i the running sum of the segment
+//    balances (:174-184) the thdd coefficients are  (m l^2 / 2) T(i,k) cc_ik  with
+//        T(i,k) = W(i,k) + W(i-1,k),  W(i,k) = sum_{j<=i} vw(j,k)
+//    (symmetric in i,k), so after scaling by -12/(m l^2) the system is
+//        Q thdd = r,   Q_ik = -6 T(i,k) cc_ik + [i=k]      (symmetric positive definite)
+//        r_i = -6 sum_{k!=i} T(i,k) thd_k^2 ss_ik
+//              - (6k/m) sum_j A(i,j) g_j cc_ij + (k l/m) thd_i + 12/(m l^2) (u_{i-1} - u_i)
+//        A(i,j) = (2i-1)/n - 2 [j<i] - [j=i]
+//    and is solved by an unpivoted LDL^T (n = 3: closed-form adjugate).
+//
+// The reduction was checked against the reference's own outputs before any kernel was
+// written (tests/golden/steps.npz, max relative difference 8e-15 over n = 2..8 and three
+// parameter sets) and tests/test_hip_parity.py checks the compiled kernels the same way.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sw {
+
+// Wave-uniform constants derived on the host from sw_params (live in SGPRs).
+struct Consts {
+    double l;        // l_i
+    double h;        // Euler step
+    double dirx, diry;
+    double kl_nm;    // k l / (n m)
+    double six_k_m;  // 6 k / m
+    double kl_m;     // k l / m
+    double c12;      // 12 / (m l^2)
+};
+
+// ---- compile-time chain weights ------------------------------------------------------
+template <int N> __host__ __device__ constexpr double wbar(int k1) { return (N - k1 + 0.5) / N; }
+template <int N> __host__ __device__ constexpr double vel_w(int j1, int k1)
+{
+    return (k1 < j1 ? 1.0 : (k1 == j1 ? 0.5 : 0.0)) - wbar<N>(k1);
+}
+template <int N> __host__ __device__ constexpr double Tw(int i1, int k1)
+{
+    return i1 < k1 ? -(2 * i1 - 1) * wbar<N>(k1)
+                   : (i1 == k1 ? 0.5 - (2 * k1 - 1) * wbar<N>(k1)
+                               : 2.0 * (i1 - k1) - (2 * i1 - 1) * wbar<N>(k1));
+}
+template <int N> __host__ __device__ constexpr double Aw(int i1, int j1)
+{
+    return (2 * i1 - 1) / (double)N - (j1 < i1 ? 2.0 : (j1 == i1 ? 1.0 : 0.0));
+}
+
+// ---- sin and cos of one angle ----------------------------------------------------------
+// Cody-Waite reduction by pi/2 (two FMAs with the fl(pi/2) / tail split; the first FMA is
+// exact) + the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4] (coefficients:
+// Sun fdlibm k_sin.c / k_cos.c, public domain).  |error| < 1 ulp for |x| < 1e5; larger or
+// non-finite arguments take the (wave-uniformly never executed) library branch.
+__device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_out)
+{
+    if (__builtin_expect(!(__builtin_fabs(x) < 1.0e5), 0)) {
+        ::sincos(x, &s_out, &c_out);
+        return;
+    }
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: integer part lands in the low bits
+    const double kd_m = __builtin_fma(x, 0.63661977236758134308, MAGIC);
+    const double kd = kd_m - MAGIC;
+    const uint32_t q = (uint32_t)__double_as_longlong(kd_m);
+    double r = __builtin_fma(-kd, 1.5707963267948966, x);       // exact
+    r = __builtin_fma(-kd, 6.123233995736766e-17, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double sr = __builtin_fma(r * z, ps, r);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    // quadrant: q&1 swaps, q&2 negates sin, (q+1)&2 negates cos
+    const bool swap = (q & 1u) != 0u;
+    const double sv = swap ? cr : sr;
+    const double cv = swap ? sr : cr;
+    const uint64_t sflip = (uint64_t)(q & 2u) << 62;
+    const uint64_t cflip = (uint64_t)((q + 1u) & 2u) << 62;
+    s_out = __longlong_as_double(__double_as_longlong(sv) ^ (long long)sflip);
+    c_out = __longlong_as_double(__double_as_longlong(cv) ^ (long long)cflip);
+}
+
+// 1/x for a well-scaled positive x: hardware estimate + two Newton steps (full fp64).
+__device__ __forceinline__ double rcp_f64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+// ---- symmetric positive definite solve ---------------------------------------------
+// Q x = b, Q symmetric (only i >= j read), unpivoted LDL^T fully unrolled.
+// Returns false when a pivot is not positive / not finite.
+template <int N>
+__device__ __forceinline__ bool spd_solve(double (&Q)[N][N], double (&b)[N])
+{
+    double D[N], rD[N];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double v[N];
+        double dj = Q[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            v[k] = Q[j][k] * D[k];
+            dj = __builtin_fma(-Q[j][k], v[k], dj);
+        }
+        D[j] = dj;
+        ok = ok && (dj > 0.0) && (dj < 1.0e300);
+        rD[j] = rcp_f64(dj);
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double a = Q[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) a = __builtin_fma(-Q[i][k], v[k], a);
+            Q[i][j] = a * rD[j];
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) b[i] = __builtin_fma(-Q[i][k], b[k], b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] *= rD[i];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) {
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) b[i] = __builtin_fma(-Q[k][i], b[k], b[i]);
+    }
+    return ok;
+}
+
+// n = 3: closed-form adjugate (one reciprocal, short dependency chain).
+template <>
+__device__ __forceinline__ bool spd_solve<3>(double (&Q)[3][3], double (&b)[3])
+{
+    const double a = Q[0][0], bb = Q[1][0], c = Q[2][0], d = Q[1][1], e = Q[2][1], f = Q[2][2];
+    const double c00 = __builtin_fma(d, f, -e * e);
+    const double c01 = __builtin_fma(c, e, -bb * f);
+    const double c02 = __builtin_fma(bb, e, -c * d);
+    const double c11 = __builtin_fma(a, f, -c * c);
+    const double c12 = __builtin_fma(bb, c, -a * e);
+    const double c22 = __builtin_fma(a, d, -bb * bb);
+    const double det = __builtin_fma(a, c00, __builtin_fma(bb, c01, c * c02));
+    const bool ok = (det > 0.0) && (det < 1.0e300) && (a > 0.0) && (c22 > 0.0);
+    const double rdet = rcp_f64(det);
+    const double x0 = __builtin_fma(c00, b[0], __builtin_fma(c01, b[1], c02 * b[2]));
+    const double x1 = __builtin_fma(c01, b[0], __builtin_fma(c11, b[1], c12 * b[2]));
+    const double x2 = __builtin_fma(c02, b[0], __builtin_fma(c12, b[1], c22 * b[2]));
+    b[0] = x0 * rdet;
+    b[1] = x1 * rdet;
+    b[2] = x2 * rdet;
+    return ok;
+}
+
+template <>
+__device__ __forceinline__ bool spd_solve<2>(double (&Q)[2][2], double (&b)[2])
+{
+    const double a = Q[0][0], bb = Q[1][0], d = Q[1][1];
+    const double det = __builtin_fma(a, d, -bb * bb);
+    const bool ok = (det > 0.0) && (det < 1.0e300) && (a > 0.0);
+    const double rdet = rcp_f64(det);
+    const double x0 = __builtin_fma(d, b[0], -bb * b[1]);
+    const double x1 = __builtin_fma(a, b[1], -bb * b[0]);
+    b[0] = x0 * rdet;
+    b[1] = x1 * rdet;
+    return ok;
+}
+
+// ---- accelerations -------------------------------------------------------------------
+// u[] holds the N-1 joint torques.  Outputs Gdd and thdd; returns false on a bad pivot.
+template <int N>
+__device__ __forceinline__ bool accelerations(const Consts &C, double gdx, double gdy,
+                                              const double (&th)[N], const double (&thd)[N],
+                                              const double (&u)[N > 1 ? N - 1 : 1],
+                                              double &gddx, double &gddy, double (&tdd)[N])
+{
+    double s[N], c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) sincos_f64(th[i], s[i], c[i]);
+
+    double cc[N][N], ss[N][N];  // cc[i][j] = cos(th_i - th_j), ss[i][k] = sin(th_k - th_i)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cc[i][i] = 1.0;
+        ss[i][i] = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) {
+            cc[i][j] = cc[j][i] = __builtin_fma(c[i], c[j], s[i] * s[j]);
+            ss[i][j] = __builtin_fma(c[i], s[j], -s[i] * c[j]);
+            ss[j][i] = -ss[i][j];
+        }
+    }
+
+    double lthd[N], thd2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        lthd[k] = C.l * thd[k];
+        thd2[k] = thd[k] * thd[k];
+    }
+
+    // g_j = Gdot_j . n_j  (normal velocity of segment j's centre, :180-182)
+    double g[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double a = __builtin_fma(gdy, c[j], -gdx * s[j]);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double w = vel_w<N>(j + 1, k + 1);
+            a = __builtin_fma(w * cc[j][k], lthd[k], a);
+        }
+        g[j] = a;
+    }
+
+    // barycentre acceleration: n m Gdd = sum_j F_j n_j, F_j = -k l g_j
+    double sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        sx = __builtin_fma(g[j], s[j], sx);
+        sy = __builtin_fma(g[j], c[j], sy);
+    }
+    gddx = C.kl_nm * sx;
+    gddy = -C.kl_nm * sy;
+
+    // right-hand side and matrix of Q thdd = r
+    double Q[N][N], r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double cent = 0.0, fric = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (k != i) cent = __builtin_fma((-6.0 * Tw<N>(i + 1, k + 1)) * thd2[k], ss[i][k], cent);
+            fric = __builtin_fma(Aw<N>(i + 1, k + 1) * cc[i][k], g[k], fric);
+        }
+        double tq = 0.0;
+        if (i >= 1) tq += u[i - 1];
+        if (i < N - 1) tq -= u[i];
+        double ri = __builtin_fma(-C.six_k_m, fric, cent);
+        ri = __builtin_fma(C.kl_m, thd[i], ri);
+        ri = __builtin_fma(C.c12, tq, ri);
+        r[i] = ri;
+#pragma unroll
+        for (int k = 0; k <= i; ++k)
+            Q[i][k] = (k == i) ? (-6.0 * Tw<N>(i + 1, i + 1) + 1.0)
+                               : (-6.0 * Tw<N>(i + 1, k + 1)) * cc[i][k];
+    }
+    const bool ok = spd_solve<N>(Q, r);
+#pragma unroll
+    for (int i = 0; i < N; ++i) tdd[i] = r[i];
+    return ok;
+}
+
+// ---- one explicit-Euler step (remy_swimmer_env.py:87-91), in place -------------------
+// reward = Gdot_new . direction (:243).
+template <int N>
+__device__ __forceinline__ bool euler_step(const Consts &C, double &gdx, double &gdy,
+                                           double (&th)[N], double (&thd)[N],
+                                           const double (&u)[N > 1 ? N - 1 : 1], double &reward)
+{
+    double gddx, gddy, tdd[N];
+    const bool ok = accelerations<N>(C, gdx, gdy, th, thd, u, gddx, gddy, tdd);
+    gdx = __builtin_fma(C.h, gddx, gdx);
+    gdy = __builtin_fma(C.h, gddy, gdy);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        th[i] = __builtin_fma(C.h, thd[i], th[i]);    // old theta_dot
+        thd[i] = __builtin_fma(C.h, tdd[i], thd[i]);
+    }
+    reward = __builtin_fma(gdx, C.dirx, gdy * C.diry);
+    return ok;
+}
+
+}  // namespace sw

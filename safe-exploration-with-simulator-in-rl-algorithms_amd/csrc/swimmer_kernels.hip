@@ -1,0 +1,605 @@
+// swimmer_kernels.hip -- gfx950 kernels + the C ABI of include/swimmer_hip.h.
+//
+// Kernels (all fp64, one swimmer / rollout per lane, no MFMA: the largest contraction on
+// this path is 8x8):
+//   step_kernel<N>      one physics step, SoA in / SoA out; HBM-bound at large n_env
+//                       (algorithmic traffic 16 (2n+2) + 8 (n-1) + 8 bytes per env-step)
+//   accel_kernel<N>     accelerations only
+//   rollout_kernel<N,ARS>  H steps with the state, the whitened policy, the return and the
+//                       V2 moment sums held in registers; optional coalesced trajectory
+//                       stores (8 (2n+2) bytes per env-step); fp64-VALU-issue bound
+//   ars_update_kernel   sigma_R, policy update, V2 statistics merge (one workgroup per
+//                       policy entry + one for the statistics)
+//   traj_moments_kernel full first/second moments of a trajectory buffer; HBM-bound
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/swimmer_hip.h"
+#include "swimmer_device.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kStepBlock = 256;
+constexpr int kRollBlock = 64;   // one wave per workgroup: every wave gets a SIMD to itself
+constexpr int kUpdBlock = 256;
+constexpr double kHalfPi = 1.57079632679489661923;  // math.pi / 2 (remy_swimmer_env.py:65)
+
+sw::Consts make_consts(const sw_params *p)
+{
+    sw::Consts c;
+    c.l = p->l_i;
+    c.h = p->h;
+    c.dirx = p->dir_x;
+    c.diry = p->dir_y;
+    c.kl_nm = p->k * p->l_i / ((double)p->n * p->m_i);
+    c.six_k_m = 6.0 * p->k / p->m_i;
+    c.kl_m = p->k * p->l_i / p->m_i;
+    c.c12 = 12.0 / (p->m_i * p->l_i * p->l_i);
+    return c;
+}
+
+int check_params(const sw_params *p)
+{
+    if (!p) return SW_ERR_NULL;
+    if (p->n < 2 || p->n > SW_MAX_SEGMENTS) return SW_ERR_SEGMENTS;
+    if (!(p->l_i > 0.0) || !(p->m_i > 0.0) || !isfinite(p->l_i) || !isfinite(p->m_i) ||
+        !isfinite(p->k) || !isfinite(p->h) || !isfinite(p->dir_x) || !isfinite(p->dir_y))
+        return SW_ERR_PARAM;
+    return SW_OK;
+}
+
+// ------------------------------------------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(kStepBlock)
+step_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
+            const double *__restrict__ act, double *__restrict__ sout,
+            double *__restrict__ reward, int32_t *__restrict__ status)
+{
+    constexpr int M = N - 1;
+    const int64_t e = (int64_t)blockIdx.x * kStepBlock + threadIdx.x;
+    if (e >= n_env) return;
+    double gdx = sin_[e], gdy = sin_[n_env + e];
+    double th[N], thd[N], u[M];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        th[i] = sin_[(int64_t)(2 + 2 * i) * n_env + e];
+        thd[i] = sin_[(int64_t)(3 + 2 * i) * n_env + e];
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) u[i] = act[(int64_t)i * n_env + e];
+    double r;
+    const bool ok = sw::euler_step<N>(C, gdx, gdy, th, thd, u, r);
+    sout[e] = gdx;
+    sout[n_env + e] = gdy;
+    bool fin = isfinite(gdx) && isfinite(gdy);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sout[(int64_t)(2 + 2 * i) * n_env + e] = th[i];
+        sout[(int64_t)(3 + 2 * i) * n_env + e] = thd[i];
+        fin = fin && isfinite(th[i]) && isfinite(thd[i]);
+    }
+    if (reward) reward[e] = r;
+    if (status) status[e] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE);
+}
+
+template <int N>
+__global__ void __launch_bounds__(kStepBlock)
+accel_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
+             const double *__restrict__ act, double *__restrict__ gdd, double *__restrict__ tdd)
+{
+    constexpr int M = N - 1;
+    const int64_t e = (int64_t)blockIdx.x * kStepBlock + threadIdx.x;
+    if (e >= n_env) return;
+    double gdx = sin_[e], gdy = sin_[n_env + e];
+    double th[N], thd[N], u[M], a[N], ax, ay;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        th[i] = sin_[(int64_t)(2 + 2 * i) * n_env + e];
+        thd[i] = sin_[(int64_t)(3 + 2 * i) * n_env + e];
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) u[i] = act[(int64_t)i * n_env + e];
+    sw::accelerations<N>(C, gdx, gdy, th, thd, u, ax, ay, a);
+    gdd[e] = ax;
+    gdd[n_env + e] = ay;
+#pragma unroll
+    for (int i = 0; i < N; ++i) tdd[(int64_t)i * n_env + e] = a[i];
+}
+
+__global__ void reset_kernel(int n, int64_t n_env, double *__restrict__ state)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_env) return;
+    state[e] = 0.0;
+    state[n_env + e] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        state[(int64_t)(2 + 2 * i) * n_env + e] = kHalfPi;
+        state[(int64_t)(3 + 2 * i) * n_env + e] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Rollouts.  ARS = false: policies[r][m][d] given per rollout.  ARS = true: rollout r is
+// direction dir_begin + (r >> 1) with sign + (r even) / - (r odd); its policy
+// P +- nu * delta is built here (ars_agent.py:141-142), so the perturbed policies never
+// exist in HBM.  The V2 whitening P diag(inv_std) (ars/environment.py:32-33) is folded into
+// the register copy of the policy once per rollout instead of once per step.
+template <int N, bool ARS>
+__global__ void __launch_bounds__(kRollBlock)
+rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict__ policies,
+               const double *__restrict__ deltas, int64_t dir_begin, double nu,
+               const double *__restrict__ mean, const double *__restrict__ inv_std,
+               const double *__restrict__ state0, double *__restrict__ returns,
+               double *__restrict__ traj, double *__restrict__ final_state,
+               double *__restrict__ moments, int32_t *__restrict__ status)
+{
+    constexpr int D = 2 * N + 2, M = N - 1;
+    const int64_t r = (int64_t)blockIdx.x * kRollBlock + threadIdx.x;
+    const bool active = r < n_roll;
+    const bool v2 = (mean != nullptr);
+
+    double m1[D], m2[D];  // V2 moment sums of (s - c), c = reset state
+#pragma unroll
+    for (int j = 0; j < D; ++j) m1[j] = m2[j] = 0.0;
+
+    if (active) {
+        // ---- policy into registers ----
+        double W[M][D], mu[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) mu[j] = v2 ? mean[j] : 0.0;
+        if (ARS) {
+            const int64_t dir = dir_begin + (r >> 1);
+            const double sgn = (r & 1) ? -1.0 : 1.0;
+            const double *dl = deltas + dir * (M * D);
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const double t = __dmul_rn(nu, dl[i * D + j]);
+                    W[i][j] = __dadd_rn(policies[i * D + j], sgn * t);
+                }
+        } else {
+            const double *pl = policies + r * (M * D);
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) W[i][j] = pl[i * D + j];
+        }
+        if (v2) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double sc = inv_std[j];
+#pragma unroll
+                for (int i = 0; i < M; ++i) W[i][j] = __dmul_rn(W[i][j], sc);
+            }
+        }
+
+        // ---- start state ----
+        double gdx, gdy, th[N], thd[N];
+        if (state0) {
+            gdx = state0[r];
+            gdy = state0[n_roll + r];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                th[i] = state0[(int64_t)(2 + 2 * i) * n_roll + r];
+                thd[i] = state0[(int64_t)(3 + 2 * i) * n_roll + r];
+            }
+        } else {
+            gdx = gdy = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                th[i] = kHalfPi;
+                thd[i] = 0.0;
+            }
+        }
+
+        double total = 0.0;
+        bool ok = true;
+        for (int32_t t = 0; t < H; ++t) {
+            // action = W (s - mu)   (ars/environment.py:29 / :34); two partial sums
+            double sm[D];
+            sm[0] = gdx - mu[0];
+            sm[1] = gdy - mu[1];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                sm[2 + 2 * i] = th[i] - mu[2 + 2 * i];
+                sm[3 + 2 * i] = thd[i] - mu[3 + 2 * i];
+            }
+            double u[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                double a0 = W[i][0] * sm[0], a1 = W[i][1] * sm[1];
+#pragma unroll
+                for (int j = 2; j < D; j += 2) {
+                    a0 = __builtin_fma(W[i][j], sm[j], a0);
+                    a1 = __builtin_fma(W[i][j + 1], sm[j + 1], a1);
+                }
+                u[i] = a0 + a1;
+            }
+            double rew;
+            ok = sw::euler_step<N>(C, gdx, gdy, th, thd, u, rew) && ok;
+            total += rew;
+            if (traj) {
+                double *tp = traj + (int64_t)t * D * n_roll + r;
+                tp[0] = gdx;
+                tp[n_roll] = gdy;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    tp[(int64_t)(2 + 2 * i) * n_roll] = th[i];
+                    tp[(int64_t)(3 + 2 * i) * n_roll] = thd[i];
+                }
+            }
+            if (moments) {
+                m1[0] += gdx;
+                m2[0] = __builtin_fma(gdx, gdx, m2[0]);
+                m1[1] += gdy;
+                m2[1] = __builtin_fma(gdy, gdy, m2[1]);
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double a = th[i] - kHalfPi;
+                    m1[2 + 2 * i] += a;
+                    m2[2 + 2 * i] = __builtin_fma(a, a, m2[2 + 2 * i]);
+                    m1[3 + 2 * i] += thd[i];
+                    m2[3 + 2 * i] = __builtin_fma(thd[i], thd[i], m2[3 + 2 * i]);
+                }
+            }
+        }
+        returns[r] = total;
+        bool fin = isfinite(gdx) && isfinite(gdy);
+#pragma unroll
+        for (int i = 0; i < N; ++i) fin = fin && isfinite(th[i]) && isfinite(thd[i]);
+        if (status) status[r] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE);
+        if (final_state) {
+            final_state[r] = gdx;
+            final_state[n_roll + r] = gdy;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                final_state[(int64_t)(2 + 2 * i) * n_roll + r] = th[i];
+                final_state[(int64_t)(3 + 2 * i) * n_roll + r] = thd[i];
+            }
+        }
+    }
+
+    if (moments) {
+        // fixed-order butterfly over the wave (deterministic), lane 0 writes the row
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double a = m1[j], b = m2[j];
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                a += __shfl_down(a, off, kWave);
+                b += __shfl_down(b, off, kWave);
+            }
+            if (threadIdx.x == 0) {
+                moments[(int64_t)blockIdx.x * (2 * D) + j] = a;
+                moments[(int64_t)blockIdx.x * (2 * D) + D + j] = b;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    const int w = threadIdx.x / kWave, l = threadIdx.x % kWave;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < kUpdBlock / kWave; ++i) t += sh[i];
+    return t;
+}
+
+// used(i): all directions (top_b == 0) or the top_b by max(r+, r-), ties to the higher index
+// (argsort ascending, reversed: ars_agent.py:105-108).
+__device__ __forceinline__ bool dir_used(const double *ret, int64_t n_dir, int64_t top_b, int64_t i)
+{
+    if (top_b <= 0 || top_b >= n_dir) return true;
+    const double ki = fmax(ret[2 * i], ret[2 * i + 1]);
+    int64_t rank = 0;
+    for (int64_t j = 0; j < n_dir; ++j) {
+        const double kj = fmax(ret[2 * j], ret[2 * j + 1]);
+        rank += (kj > ki) || (kj == ki && j > i);
+    }
+    return rank < top_b;
+}
+
+// grid = m*d + 1 workgroups.  Workgroup e < m*d updates policy entry e; the last one merges
+// the V2 statistics.  Every workgroup recomputes sigma_R (2 n_dir values, L2-resident).
+__global__ void __launch_bounds__(kUpdBlock)
+ars_update_kernel(int d, int md, int64_t n_dir, const double *__restrict__ ret,
+                  const double *__restrict__ deltas, double *__restrict__ policy, double alpha,
+                  double b, int64_t top_b, const double *__restrict__ moments,
+                  int64_t n_rows, double *__restrict__ running, double n_new,
+                  double *__restrict__ mean, double *__restrict__ inv_std,
+                  double *__restrict__ sigma_out)
+{
+    __shared__ double sh[kUpdBlock / kWave];
+    const int e = blockIdx.x;
+    if (e < md) {
+        // np.std(used_rewards): two-pass, ddof = 0 (ars_agent.py:123)
+        double s = 0.0, cnt = 0.0;
+        for (int64_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+            if (dir_used(ret, n_dir, top_b, i)) {
+                s += ret[2 * i] + ret[2 * i + 1];
+                cnt += 2.0;
+            }
+        s = block_sum(s, sh);
+        cnt = block_sum(cnt, sh);
+        const double mu = s / cnt;
+        double v = 0.0, g = 0.0;
+        for (int64_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+            if (dir_used(ret, n_dir, top_b, i)) {
+                const double a = ret[2 * i] - mu, c = ret[2 * i + 1] - mu;
+                v += a * a + c * c;
+                g = __builtin_fma(ret[2 * i] - ret[2 * i + 1], deltas[i * md + e], g);
+            }
+        v = block_sum(v, sh);
+        g = block_sum(g, sh);
+        if (threadIdx.x == 0) {
+            const double sigma = sqrt(v / cnt);
+            const double grad = g / (b * sigma);            // ars_agent.py:128
+            policy[e] = policy[e] + alpha * grad;           // ars_agent.py:130
+            if (e == 0 && sigma_out) *sigma_out = sigma;
+        }
+    } else if (running != nullptr) {
+        // V2: merge this iteration's per-workgroup partial sums (fixed order) into the
+        // running sums, then mean = c + S1/n, var = (S2 - S1^2/n)/(n-1) (np.cov, ddof = 1)
+        const int j = threadIdx.x;
+        if (j < 2 * d) {
+            double a = 0.0;
+            for (int64_t row = 0; row < n_rows; ++row) a += moments[row * (2 * d) + j];
+            running[1 + j] += a;
+        }
+        __syncthreads();
+        if (j == 0) running[0] += n_new;
+        __syncthreads();
+        if (j < d) {
+            const double n = running[0];
+            const double s1 = running[1 + j], s2 = running[1 + d + j];
+            const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
+            mean[j] = c + s1 / n;
+            const double var = (s2 - s1 * (s1 / n)) / (n - 1.0);
+            inv_std[j] = 1.0 / sqrt(var);                    // diag(cov) ** -0.5
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Full moments of traj[H][D][R].  Workgroup (bx, by): rollouts bx*256.., steps by*TCHUNK..;
+// every load is a coalesced row segment; partial sums are reduced over the workgroup and
+// added to acc with fp64 atomics (d + d(d+1)/2 + 1 atomics per workgroup).
+constexpr int kMomBlock = 256;
+constexpr int kMomTChunk = 32;
+
+template <int D>
+__global__ void __launch_bounds__(kMomBlock)
+traj_moments_kernel(int64_t n_roll, int32_t H, const double *__restrict__ traj,
+                    double *__restrict__ acc)
+{
+    constexpr int NP = D * (D + 1) / 2;
+    __shared__ double sh[kMomBlock / kWave][D + NP];
+    const int64_t r = (int64_t)blockIdx.x * kMomBlock + threadIdx.x;
+    const int32_t t0 = blockIdx.y * kMomTChunk;
+    const int32_t t1 = min(H, t0 + kMomTChunk);
+    double s1[D], s2[NP];
+#pragma unroll
+    for (int j = 0; j < D; ++j) s1[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) s2[j] = 0.0;
+    if (r < n_roll) {
+        for (int32_t t = t0; t < t1; ++t) {
+            const double *tp = traj + (int64_t)t * D * n_roll + r;
+            double x[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
+                x[j] = tp[(int64_t)j * n_roll] - c;
+            }
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                s1[j] += x[j];
+#pragma unroll
+                for (int g = j; g < D; ++g) {
+                    s2[q] = __builtin_fma(x[j], x[g], s2[q]);
+                    ++q;
+                }
+            }
+        }
+    }
+    const int w = threadIdx.x / kWave, l = threadIdx.x % kWave;
+#pragma unroll
+    for (int j = 0; j < D + NP; ++j) {
+        double v = (j < D) ? s1[j < D ? j : 0] : s2[j >= D ? j - D : 0];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+        if (l == 0) sh[w][j] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < D + NP; j += kMomBlock) {
+        double v = 0.0;
+        for (int i = 0; i < kMomBlock / kWave; ++i) v += sh[i][j];
+        if (j < D) {
+            atomicAdd(&acc[1 + j], v);
+        } else {
+            // unpack upper-triangle index -> (f, g), mirror into both halves
+            int q = j - D, f = 0;
+            while (q >= D - f) { q -= D - f; ++f; }
+            const int g = f + q;
+            atomicAdd(&acc[1 + D + f * D + g], v);
+            if (g != f) atomicAdd(&acc[1 + D + g * D + f], v);
+        }
+    }
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+        const int64_t nr = min<int64_t>(kMomBlock, n_roll - (int64_t)blockIdx.x * kMomBlock);
+        atomicAdd(&acc[0], (double)nr * (double)H);
+    }
+}
+
+// ---- dispatch on the segment count -------------------------------------------------
+#define SW_DISPATCH_N(n, CALL)                 \
+    switch (n) {                               \
+    case 2: { constexpr int NN = 2; CALL; } break; \
+    case 3: { constexpr int NN = 3; CALL; } break; \
+    case 4: { constexpr int NN = 4; CALL; } break; \
+    case 5: { constexpr int NN = 5; CALL; } break; \
+    case 6: { constexpr int NN = 6; CALL; } break; \
+    case 7: { constexpr int NN = 7; CALL; } break; \
+    case 8: { constexpr int NN = 8; CALL; } break; \
+    default: return SW_ERR_SEGMENTS;           \
+    }
+
+int launch_status()
+{
+    return hipGetLastError() == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int sw_abi_version(void) { return SW_ABI_VERSION; }
+int sw_max_segments(void) { return SW_MAX_SEGMENTS; }
+
+const char *sw_strerror(int code)
+{
+    switch (code) {
+    case SW_OK: return "ok";
+    case SW_ERR_NULL: return "a required pointer is NULL";
+    case SW_ERR_SEGMENTS: return "number of segments outside 2..8";
+    case SW_ERR_SIZE: return "bad size argument";
+    case SW_ERR_PARAM: return "non-finite or non-positive physical parameter";
+    case SW_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown error code";
+    }
+}
+
+int64_t sw_moments_blocks(int64_t n_roll)
+{
+    return n_roll <= 0 ? 0 : (n_roll + kRollBlock - 1) / kRollBlock;
+}
+
+int sw_reset_f64(const sw_params *p, int64_t n_env, double *state, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!state) return SW_ERR_NULL;
+    if (n_env < 0) return SW_ERR_SIZE;
+    if (n_env == 0) return SW_OK;
+    const unsigned grid = (unsigned)((n_env + 255) / 256);
+    hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p->n, n_env, state);
+    return launch_status();
+}
+
+int sw_step_f64(const sw_params *p, int64_t n_env, const double *state_in, const double *action,
+                double *state_out, double *reward, int32_t *status, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_env < 0) return SW_ERR_SIZE;
+    if (n_env == 0) return SW_OK;
+    if (!state_in || !action || !state_out) return SW_ERR_NULL;
+    const sw::Consts C = make_consts(p);
+    const unsigned grid = (unsigned)((n_env + kStepBlock - 1) / kStepBlock);
+    SW_DISPATCH_N(p->n, hipLaunchKernelGGL(step_kernel<NN>, dim3(grid), dim3(kStepBlock), 0,
+                                           (hipStream_t)stream, C, n_env, state_in, action,
+                                           state_out, reward, status));
+    return launch_status();
+}
+
+int sw_accel_f64(const sw_params *p, int64_t n_env, const double *state, const double *action,
+                 double *gdd, double *tdd, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_env < 0) return SW_ERR_SIZE;
+    if (n_env == 0) return SW_OK;
+    if (!state || !action || !gdd || !tdd) return SW_ERR_NULL;
+    const sw::Consts C = make_consts(p);
+    const unsigned grid = (unsigned)((n_env + kStepBlock - 1) / kStepBlock);
+    SW_DISPATCH_N(p->n, hipLaunchKernelGGL(accel_kernel<NN>, dim3(grid), dim3(kStepBlock), 0,
+                                           (hipStream_t)stream, C, n_env, state, action, gdd, tdd));
+    return launch_status();
+}
+
+int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *policies,
+                   const double *mean, const double *inv_std, const double *state0,
+                   double *returns, double *traj, double *final_state, double *moments,
+                   int32_t *status, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_roll < 0 || H < 0) return SW_ERR_SIZE;
+    if (n_roll == 0) return SW_OK;
+    if (!policies || !returns) return SW_ERR_NULL;
+    if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
+    const sw::Consts C = make_consts(p);
+    const unsigned grid = (unsigned)sw_moments_blocks(n_roll);
+    SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, false>), dim3(grid), dim3(kRollBlock),
+                                           0, (hipStream_t)stream, C, n_roll, H, policies,
+                                           (const double *)nullptr, (int64_t)0, 0.0, mean, inv_std,
+                                           state0, returns, traj, final_state, moments, status));
+    return launch_status();
+}
+
+int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, int32_t H,
+                        const double *policy, const double *deltas, double nu, const double *mean,
+                        const double *inv_std, double *returns, double *traj, double *moments,
+                        int32_t *status, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_dir < 0 || H < 0 || dir_begin < 0) return SW_ERR_SIZE;
+    if (n_dir == 0) return SW_OK;
+    if (!policy || !deltas || !returns) return SW_ERR_NULL;
+    if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
+    const sw::Consts C = make_consts(p);
+    const int64_t n_roll = 2 * n_dir;
+    const unsigned grid = (unsigned)sw_moments_blocks(n_roll);
+    SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, true>), dim3(grid), dim3(kRollBlock),
+                                           0, (hipStream_t)stream, C, n_roll, H, policy, deltas,
+                                           dir_begin, nu, mean, inv_std, (const double *)nullptr,
+                                           returns, traj, (double *)nullptr, moments, status));
+    return launch_status();
+}
+
+int sw_ars_update_f64(const sw_params *p, int64_t n_dir, const double *returns,
+                      const double *deltas, double *policy, double alpha, double b, int64_t top_b,
+                      const double *moments, int64_t n_moment_rows, double *running,
+                      int64_t n_new_states, double *mean, double *inv_std, double *sigma_out,
+                      void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_dir <= 0 || n_moment_rows < 0 || n_new_states < 0) return SW_ERR_SIZE;
+    if (!returns || !deltas || !policy) return SW_ERR_NULL;
+    if (running && (!moments || !mean || !inv_std)) return SW_ERR_NULL;
+    const int d = 2 * p->n + 2, md = (p->n - 1) * d;
+    hipLaunchKernelGGL(ars_update_kernel, dim3(md + 1), dim3(kUpdBlock), 0, (hipStream_t)stream, d,
+                       md, n_dir, returns, deltas, policy, alpha, b, top_b, moments, n_moment_rows,
+                       running, (double)n_new_states, mean, inv_std, sigma_out);
+    return launch_status();
+}
+
+int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
+                        double *acc, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_roll < 0 || H < 0) return SW_ERR_SIZE;
+    if (n_roll == 0 || H == 0) return SW_OK;
+    if (!traj || !acc) return SW_ERR_NULL;
+    const dim3 grid((unsigned)((n_roll + kMomBlock - 1) / kMomBlock),
+                    (unsigned)((H + kMomTChunk - 1) / kMomTChunk));
+    SW_DISPATCH_N(p->n, hipLaunchKernelGGL(traj_moments_kernel<2 * NN + 2>, grid, dim3(kMomBlock), 0,
+                                           (hipStream_t)stream, n_roll, H, traj, acc));
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""Functional wrappers: torch device tensors in, one C-ABI call (include/swimmer_hip.h) each.
+
+Shapes follow the ABI: states are SoA [d, n_env], actions [m, n_env], policies AoS
+[n_roll, m, d], trajectories [H, d, n_roll].  Everything is float64 and stays on the GPU;
+all calls are asynchronous on torch's current stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import SwParams, check, load, ptr, require_gpu, stream_ptr
+
+
+def _f64(shape, device):
+    return torch.empty(shape, dtype=torch.float64, device=device)
+
+
+def _want(t, name, shape):
+    if t.dtype != torch.float64 or tuple(t.shape) != tuple(shape):
+        raise _lib.SwimmerHipError(f"{name}: expected float64 tensor of shape {tuple(shape)}, "
+                                   f"got {t.dtype} {tuple(t.shape)}")
+    return t
+
+
+def reset(p: SwParams, n_env: int, device="cuda:0", out=None):
+    """SwimmerEnv.reset for n_env swimmers -> state [d, n_env]."""
+    require_gpu()
+    state = _f64((p.d, n_env), device) if out is None else _want(out, "out", (p.d, n_env))
+    check(load().sw_reset_f64(ctypes.byref(p), n_env, ptr(state), stream_ptr()), "sw_reset_f64")
+    return state
+
+
+def step(p: SwParams, state, action, out=None, reward=None, status=None):
+    """One physics step.  Returns (next_state [d, n_env], reward [n_env])."""
+    require_gpu()
+    n_env = state.shape[1]
+    _want(state, "state", (p.d, n_env))
+    _want(action, "action", (p.m, n_env))
+    out = _f64((p.d, n_env), state.device) if out is None else _want(out, "out", (p.d, n_env))
+    reward = _f64((n_env,), state.device) if reward is None else _want(reward, "reward", (n_env,))
+    check(load().sw_step_f64(ctypes.byref(p), n_env, ptr(state), ptr(action), ptr(out),
+                             ptr(reward), ptr(status), stream_ptr()), "sw_step_f64")
+    return out, reward
+
+
+def accelerations(p: SwParams, state, action):
+    """SwimmerEnv.compute_accelerations -> (Gdd [2, n_env], thdd [n, n_env])."""
+    require_gpu()
+    n_env = state.shape[1]
+    _want(state, "state", (p.d, n_env))
+    _want(action, "action", (p.m, n_env))
+    gdd = _f64((2, n_env), state.device)
+    tdd = _f64((p.n, n_env), state.device)
+    check(load().sw_accel_f64(ctypes.byref(p), n_env, ptr(state), ptr(action), ptr(gdd),
+                              ptr(tdd), stream_ptr()), "sw_accel_f64")
+    return gdd, tdd
+
+
+def moments_blocks(n_roll: int) -> int:
+    return int(load().sw_moments_blocks(n_roll))
+
+
+def rollout(p: SwParams, H: int, policies, mean=None, inv_std=None, state0=None,
+            traj=None, final_state=None, moments=None, status=None, returns=None):
+    """n_roll H-step rollouts, one linear policy each.  Optional output buffers are filled
+    when given (see include/swimmer_hip.h for their shapes).  Returns `returns` [n_roll]."""
+    require_gpu()
+    n_roll = policies.shape[0]
+    _want(policies, "policies", (n_roll, p.m, p.d))
+    dev = policies.device
+    if (mean is None) != (inv_std is None):
+        raise _lib.SwimmerHipError("mean and inv_std must be given together")
+    if mean is not None:
+        _want(mean, "mean", (p.d,))
+        _want(inv_std, "inv_std", (p.d,))
+    if state0 is not None:
+        _want(state0, "state0", (p.d, n_roll))
+    if traj is not None:
+        _want(traj, "traj", (H, p.d, n_roll))
+    if final_state is not None:
+        _want(final_state, "final_state", (p.d, n_roll))
+    if moments is not None:
+        _want(moments, "moments", (moments_blocks(n_roll), 2 * p.d))
+    returns = _f64((n_roll,), dev) if returns is None else _want(returns, "returns", (n_roll,))
+    check(load().sw_rollout_f64(ctypes.byref(p), n_roll, H, ptr(policies), ptr(mean),
+                                ptr(inv_std), ptr(state0), ptr(returns), ptr(traj),
+                                ptr(final_state), ptr(moments), ptr(status), stream_ptr()),
+          "sw_rollout_f64")
+    return returns
+
+
+def ars_rollouts(p: SwParams, H: int, policy, deltas, nu: float, dir_begin: int, n_dir: int,
+                 mean=None, inv_std=None, returns=None, traj=None, moments=None, status=None):
+    """The 2*n_dir exploration rollouts P +- nu*delta_i, i in [dir_begin, dir_begin+n_dir)."""
+    require_gpu()
+    _want(policy, "policy", (p.m, p.d))
+    if deltas.dim() != 3 or deltas.shape[0] < dir_begin + n_dir:
+        raise _lib.SwimmerHipError("deltas: need [>= dir_begin + n_dir, m, d]")
+    _want(deltas, "deltas", (deltas.shape[0], p.m, p.d))
+    dev = policy.device
+    n_roll = 2 * n_dir
+    if (mean is None) != (inv_std is None):
+        raise _lib.SwimmerHipError("mean and inv_std must be given together")
+    if traj is not None:
+        _want(traj, "traj", (H, p.d, n_roll))
+    if moments is not None:
+        _want(moments, "moments", (moments_blocks(n_roll), 2 * p.d))
+    returns = _f64((n_roll,), dev) if returns is None else _want(returns, "returns", (n_roll,))
+    check(load().sw_ars_rollouts_f64(ctypes.byref(p), dir_begin, n_dir, H, ptr(policy),
+                                     ptr(deltas), float(nu), ptr(mean), ptr(inv_std),
+                                     ptr(returns), ptr(traj), ptr(moments), ptr(status),
+                                     stream_ptr()), "sw_ars_rollouts_f64")
+    return returns
+
+
+def ars_update(p: SwParams, returns, deltas, policy, alpha: float, b: float, top_b: int = 0,
+               moments=None, running=None, n_new_states: int = 0, mean=None, inv_std=None,
+               sigma_out=None):
+    """In-place ARS update of `policy` (+ V2 statistics when `running` is given)."""
+    require_gpu()
+    n_dir = returns.shape[0] // 2
+    _want(returns, "returns", (2 * n_dir,))
+    _want(policy, "policy", (p.m, p.d))
+    _want(deltas, "deltas", (deltas.shape[0], p.m, p.d))
+    if deltas.shape[0] < n_dir:
+        raise _lib.SwimmerHipError("deltas: fewer directions than returns")
+    n_rows = 0
+    if running is not None:
+        _want(running, "running", (1 + 2 * p.d,))
+        _want(mean, "mean", (p.d,))
+        _want(inv_std, "inv_std", (p.d,))
+        n_rows = moments.shape[0]
+        _want(moments, "moments", (n_rows, 2 * p.d))
+    check(load().sw_ars_update_f64(ctypes.byref(p), n_dir, ptr(returns), ptr(deltas),
+                                   ptr(policy), float(alpha), float(b), int(top_b),
+                                   ptr(moments), n_rows, ptr(running), int(n_new_states),
+                                   ptr(mean), ptr(inv_std), ptr(sigma_out), stream_ptr()),
+          "sw_ars_update_f64")
+    return policy
+
+
+def traj_moments(p: SwParams, traj, acc=None):
+    """acc [1 + d + d*d] += {count, sum(s-c), sum((s-c)(s-c)^T)} over traj [H, d, n_roll]."""
+    require_gpu()
+    H, d, n_roll = traj.shape
+    _want(traj, "traj", (H, p.d, n_roll))
+    if acc is None:
+        acc = torch.zeros(1 + d + d * d, dtype=torch.float64, device=traj.device)
+    _want(acc, "acc", (1 + d + d * d,))
+    check(load().sw_traj_moments_f64(ctypes.byref(p), n_roll, H, ptr(traj), ptr(acc),
+                                     stream_ptr()), "sw_traj_moments_f64")
+    return acc

@@ -1,0 +1,251 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the golden vectors
+the reference produced.  Tolerance contract (BASELINE.json north_star): 1e-5 absolute,
+step for step, in fp64.  The asserted bounds are far tighter (what the reduced-algebra
+kernel actually achieves), so a regression shows long before the contract is at risk."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import PARAM_SETS
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT_TOL = 1e-5
+STEP_TOL = 1e-12        # one step, |state| <= ~3
+ACC_RTOL = 1e-12        # accelerations, relative to max |thdd|
+TRAJ_TOL = 1e-9         # 1000-step trajectories
+
+
+@pytest.fixture(scope="module")
+def sw():
+    import swimmer_amd
+    swimmer_amd._lib.load()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return swimmer_amd
+
+
+def soa(x):
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x).T), device="cuda:0")
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("pset", list(PARAM_SETS))
+def test_step_vs_reference_golden(sw, golden, n, pset):
+    g = golden.steps
+    l, m, k, h = PARAM_SETS[pset]
+    key = f"n{n}_{pset}"
+    p = sw.SwParams.make(n, l, m, k, h, g[key + "_dir"])
+    st, ac = soa(g[key + "_state"]), soa(g[key + "_action"])
+    status = torch.zeros(st.shape[1], dtype=torch.int32, device="cuda:0")
+    nxt, rew = sw.kernels.step(p, st, ac, status=status)
+    gdd, tdd = sw.kernels.accelerations(p, st, ac)
+    nxt, rew = nxt.T.cpu().numpy(), rew.cpu().numpy()
+    assert int(status.abs().sum()) == 0
+    assert np.abs(nxt - g[key + "_next"]).max() <= STEP_TOL
+    assert np.abs(rew - g[key + "_reward"]).max() <= STEP_TOL
+    ref_t = g[key + "_tdd"]
+    assert np.abs(tdd.T.cpu().numpy() - ref_t).max() <= ACC_RTOL * np.abs(ref_t).max()
+    assert np.abs(gdd.T.cpu().numpy() - g[key + "_gdd"]).max() <= ACC_RTOL * 10
+
+
+def test_config2_8192_envs_vs_oracle(sw):
+    """BASELINE config 2: n = 3, 8192 envs, one physics step, SURVEY 8d C2 distributions."""
+    rng = np.random.default_rng(0)
+    B, n = 8192, 3
+    for pset in ("default", "realworld"):
+        l, m, k, h = PARAM_SETS[pset]
+        st = np.empty((B, 8))
+        st[:, 0:2] = rng.uniform(-0.5, 0.5, (B, 2))
+        st[:, 2::2] = rng.uniform(-np.pi, np.pi, (B, n))
+        st[:, 3::2] = rng.uniform(-2, 2, (B, n))
+        ac = rng.uniform(-5, 5, (B, 2))
+        ref_next, ref_rew = oracle.step_batch(oracle.OracleParams.make(n, l, m, k, h), st, ac)
+        nxt, rew = sw.kernels.step(sw.SwParams.make(n, l, m, k, h), soa(st), soa(ac))
+        nxt = nxt.T.cpu().numpy()
+        err = np.abs(nxt - ref_next).max()
+        bit = float((nxt == ref_next).mean())
+        print(f"config2 {pset}: max|err| = {err:.3e}, bit-identical doubles = {bit:.4f}")
+        assert err <= STEP_TOL
+        assert np.abs(rew.cpu().numpy() - ref_rew).max() <= STEP_TOL
+
+
+def test_known_answers(sw, golden):
+    k = golden.kat
+    p = sw.SwParams.make(3)
+    assert np.array_equal(sw.kernels.reset(p, 5).T.cpu().numpy(), np.tile(k["reset"], (5, 1)))
+    env = sw.SwimmerEnv()
+    assert env.reset() == k["reset"].tolist()
+    ob, r, done, info = env.step([2.5, 2.5])
+    assert done is False and info == {}
+    assert np.abs(np.array(ob) - k["reset_step_u25"]).max() < 1e-15
+    for tag in ("u0", "u25", "u5m5"):
+        env.set_state(k["kat_state"].tolist())
+        G, T = env.compute_accelerations(k[f"kat_{tag}_u"], env.G_dot, env.theta, env.theta_dot)
+        assert np.abs(G - k[f"kat_{tag}_gdd"]).max() < 1e-13
+        assert np.abs(T - k[f"kat_{tag}_tdd"]).max() < 1e-12
+    env.set_state(k["kat_state"].tolist())
+    G, _ = env.compute_accelerations([0.0, 0.0], env.G_dot, env.theta, env.theta_dot)
+    assert abs(G[0] - 0.284343) < 1e-6   # Coulom's program, acceleration-compare.txt:6
+
+
+def test_gym_surface_step_for_step(sw, golden):
+    """Drive the Gym-style env exactly like the reference's __main__ (seed-23 scenario)."""
+    t = golden.trajectories
+    env = sw.SwimmerEnv()
+    env.set_state(t["main23_state0"].tolist())
+    total = 0.0
+    for i in range(200):
+        ob, r, done, _ = env.step(np.zeros(2))
+        assert isinstance(ob, list) and len(ob) == 8 and done is False
+        assert np.abs(np.array(ob) - t["main23_traj"][i]).max() <= 1e-11
+        assert abs(r - t["main23_rewards"][i]) <= 1e-12
+        total += r
+
+
+def _traj_keys(t):
+    return [x[:-len("_return")] for x in t.files if x.endswith("_return")]
+
+
+def test_rollouts_vs_reference_golden(sw, golden):
+    t = golden.trajectories
+    worst = 0.0
+    for key in _traj_keys(t):
+        n = int(key.split("_n")[1][0])
+        l, m, k, h = PARAM_SETS[key.split("_")[2]]
+        H = t[key + "_traj"].shape[0]
+        ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)
+        env = sw.Environment(ep)
+        mean = t[key + "_mean"] if key + "_mean" in t.files else None
+        cov = t[key + "_cov"] if key + "_cov" in t.files else None
+        ret, states = env.rollout(t[key + "_policy"], covariance=cov, mean=mean)
+        assert isinstance(ret, float) and len(states) == H and len(states[0]) == 2 * n + 2
+        err = np.abs(np.array(states) - t[key + "_traj"]).max()
+        worst = max(worst, err)
+        assert err <= TRAJ_TOL, key
+        assert abs(ret - float(t[key + "_return"])) <= 1e-9 * max(1.0, abs(float(t[key + "_return"]))), key
+    print(f"worst trajectory deviation over {len(_traj_keys(t))} reference rollouts: {worst:.3e}")
+
+
+def test_rollout_batch_vs_oracle_and_moments(sw):
+    """Many different policies at once (ragged last wave), V2 whitening, start states,
+    final states and the fused moment sums."""
+    rng = np.random.default_rng(5)
+    for n, R, H in ((3, 200, 300), (6, 70, 120), (2, 1, 50), (4, 65, 64)):
+        d, m = 2 * n + 2, n - 1
+        l, mm, k, h = PARAM_SETS["realworld"]
+        pol = 0.1 * rng.uniform(-1, 1, (R, m, d))
+        mean = 0.05 * rng.standard_normal(d)
+        mean[2::2] += np.pi / 2
+        var = rng.uniform(0.3, 2.0, d)
+        op = oracle.OracleParams.make(n, l, mm, k, h)
+        ref_ret, ref_traj = oracle.rollout_batch(op, H, pol, mean, var, want_traj=True)
+        p = sw.SwParams.make(n, l, mm, k, h)
+        dev = "cuda:0"
+        traj = torch.empty((H, d, R), dtype=torch.float64, device=dev)
+        fin = torch.empty((d, R), dtype=torch.float64, device=dev)
+        mom = torch.zeros((sw.kernels.moments_blocks(R), 2 * d), dtype=torch.float64, device=dev)
+        status = torch.zeros(R, dtype=torch.int32, device=dev)
+        ret = sw.kernels.rollout(p, H, torch.as_tensor(pol, device=dev),
+                                 mean=torch.as_tensor(mean, device=dev),
+                                 inv_std=torch.as_tensor(var ** -0.5, device=dev),
+                                 traj=traj, final_state=fin, moments=mom, status=status)
+        tr = traj.permute(2, 0, 1).cpu().numpy()
+        assert np.abs(tr - ref_traj).max() <= TRAJ_TOL
+        assert np.abs(ret.cpu().numpy() - ref_ret).max() <= 1e-9
+        assert np.array_equal(fin.T.cpu().numpy(), tr[:, -1, :])
+        assert int(status.abs().sum()) == 0
+        c = np.zeros(d)
+        c[2::2] = np.pi / 2
+        x = ref_traj.reshape(-1, d) - c
+        ms = mom.sum(0).cpu().numpy()
+        assert np.allclose(ms[:d], x.sum(0), rtol=1e-9, atol=1e-9)
+        assert np.allclose(ms[d:], (x * x).sum(0), rtol=1e-9, atol=1e-9)
+        # full moments kernel over the recorded trajectories
+        acc = sw.kernels.traj_moments(p, traj).cpu().numpy()
+        assert acc[0] == R * H
+        assert np.allclose(acc[1:1 + d], x.sum(0), rtol=1e-9, atol=1e-9)
+        assert np.allclose(acc[1 + d:].reshape(d, d), x.T @ x, rtol=1e-9, atol=1e-8)
+        # start states: continue every rollout from its final state, V1 action path
+        ref2 = [oracle.rollout(op, 20, pol[r], state0=ref_traj[r, -1])[0] for r in range(R)]
+        ret2 = sw.kernels.rollout(p, 20, torch.as_tensor(pol, device=dev), state0=fin)
+        assert np.abs(ret2.cpu().numpy() - np.array(ref2)).max() <= 1e-9
+
+
+def test_edge_cases(sw):
+    p = sw.SwParams.make(3)
+    dev = "cuda:0"
+    e = torch.empty((8, 0), dtype=torch.float64, device=dev)
+    a = torch.empty((2, 0), dtype=torch.float64, device=dev)
+    nxt, rew = sw.kernels.step(p, e, a)                       # empty batch is a no-op
+    assert nxt.shape == (8, 0) and rew.shape == (0,)
+    r = sw.kernels.rollout(p, 0, torch.zeros((3, 2, 8), dtype=torch.float64, device=dev))
+    assert torch.equal(r, torch.zeros(3, dtype=torch.float64, device=dev))   # H = 0
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.reset(sw.SwParams.make(9), 4)              # n outside 2..8
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.reset(sw.SwParams.make(3, l_i=0.0), 4)     # non-positive length
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.step(p, torch.zeros((8, 4), dtype=torch.float64, device=dev),
+                        torch.zeros((3, 4), dtype=torch.float64, device=dev))
+    # non-finite input is reported, not hidden
+    st = sw.kernels.reset(p, 64)
+    st[2, 7] = float("nan")
+    status = torch.zeros(64, dtype=torch.int32, device=dev)
+    sw.kernels.step(p, st, torch.zeros((2, 64), dtype=torch.float64, device=dev), status=status)
+    assert int(status[7]) != 0 and int(status.abs().sum()) == int(status[7])
+    # large angles take the library sincos branch and still agree with the oracle
+    big = np.array([[0.1, -0.2, 1.0e6 + 0.5, 0.3, -2.5e7, -0.1, 12345.678, 0.2]])
+    ref, _ = oracle.step_batch(oracle.OracleParams.make(3), big, np.array([[1.0, -1.0]]))
+    out, _ = sw.kernels.step(p, soa(big), soa(np.array([[1.0, -1.0]])))
+    assert np.abs(out.T.cpu().numpy() - ref).max() <= 1e-9   # |theta| ~ 1e7: ulp(theta) = 2e-9
+
+
+ARS_CASES = ["v2_n3_N4_H50", "v2_n3_N8_H50", "v2_n3_N4_H1000", "v2_n3_N6_H200_rw",
+             "v1_n3_N4_H100", "v2_n6_N4_H100", "v1_n3_N1_H1000"]
+
+
+def cov_close(c, ref, rel):
+    sd = np.sqrt(np.diag(ref))
+    return bool((np.abs(c - ref) <= rel * np.outer(sd, sd)).all())
+
+
+@pytest.mark.parametrize("tag", ARS_CASES)
+def test_ars_iterations_vs_reference_golden(sw, golden, tag):
+    a = golden.ars
+    n, V1, N, b, H, seed, iters = [int(x) for x in a[tag + "_cfg"]]
+    l, m, k, h, alpha, nu = [float(x) for x in a[tag + "_phys"]]
+    ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)
+    ap = sw.ARSParam("Test", V1=bool(V1), n_iter=iters, H=H, N=N, b=b, alpha=alpha, nu=nu,
+                     safe=False, threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=seed)
+    for it in range(iters):
+        r = np.array(agent.runOneIteration())
+        ref = a[tag + "_rewards"][it]
+        assert r.shape == (2 * N,)
+        assert np.abs(r - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (tag, it)
+        perr = np.abs(agent.policy - a[tag + "_policies"][it]).max()
+        print(f"{tag} it{it}: max|dP| = {perr:.3e}, max|dR| = {np.abs(r - ref).max():.3e}")
+        assert perr <= (1e-6 if H <= 50 else 1e-9), (tag, it)
+        assert perr <= CONTRACT_TOL
+        if not V1:
+            assert np.abs(agent.mean - a[tag + "_means"][it]).max() <= 1e-8
+            assert cov_close(agent.covariance, a[tag + "_covs"][it], 1e-5), (tag, it)
+    if not V1:
+        assert agent.n_saved_states == int(a[tag + "_nstates"])
+
+
+def test_ars_training_and_store(sw, golden, tmp_path):
+    a = golden.ars
+    ep = sw.EnvParam("LeonSwimmer-Test", n=3, H=60, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("Test", V1=False, n_iter=4, H=60, N=3, b=3, alpha=0.0075, nu=0.01,
+                     safe=False, threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=5, record_trajectories=True)
+    curve = agent.runTraining(save_policy_path=str(tmp_path / "pol.npy"))
+    assert curve.shape == (5,)
+    assert np.abs(curve - a["train_v2_n3_N3_H60_curve"]).max() < 1e-14
+    assert np.abs(np.load(tmp_path / "pol.npy") - a["train_v2_n3_N3_H60_policy"]).max() < 1e-6
+    # trajectory store in the reference's .npz format (ars/database.py:37)
+    agent.database.save(str(tmp_path / "db.npz"))
+    z = np.load(tmp_path / "db.npz")
+    assert z["policies"].shape == (5 * 6, 2, 8) and z["trajectories"].shape == (5 * 6, 60, 8)
