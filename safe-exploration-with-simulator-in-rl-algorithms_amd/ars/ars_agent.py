@@ -78,6 +78,7 @@ class ARSAgent(object):
             if self.full_covariance else None
         self._sigma = torch.zeros(1, **f64)
         self.n_saved_states = 0
+        self.kernel_events = None  # set to [] to collect (start, end) events per rollout launch
 
         N, H = agent_param.N, agent_param.H
         self.lo, self.hi, self.chunk = shard_bounds(N, self.rank, self.world)
@@ -173,11 +174,18 @@ class ARSAgent(object):
             deltas = self.sample_deltas()
         self._upload_deltas(deltas)
         if self.n_local > 0:
+            if self.kernel_events is not None:   # HIP events on the launch stream (bench.py)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             kernels.ars_rollouts(self.params, ap.H, self._policy, self._deltas, ap.nu,
                                  self.lo, self.n_local, mean=self._mean,
                                  inv_std=self._inv_std, returns=self._returns_local,
                                  traj=self._traj, moments=self._moments_local,
                                  status=self._status)
+            if self.kernel_events is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.kernel_events.append((e0, e1))
         returns_all, moments_all = exchange(self._returns_local, self._moments_local, ap.N,
                                             self.world, self.group, self.rows_chunk)
         n_new = 2 * ap.N * ap.H
