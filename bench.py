@@ -58,6 +58,7 @@ def cpu_baseline(n, H, directions, seconds):
     batches of the benchmark's shape until `seconds` have elapsed."""
     import oracle
     oracle.build()
+    oracle.set_num_threads(oracle.cpu_share())
     p = oracle.OracleParams.make(n)
     d, m = 2 * n + 2, n - 1
     rng = np.random.RandomState(0)

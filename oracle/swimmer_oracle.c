@@ -29,6 +29,9 @@
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "swimmer_oracle.h"
 
@@ -240,6 +243,25 @@ int swo_rollout(const swo_params *p, int H, const double *policy, const double *
     }
     *ret = total;
     return 0;
+}
+
+/* Threads the batched variants run on (1 without OpenMP). */
+int swo_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void swo_set_num_threads(int t)
+{
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
 }
 
 /* Batched variants.  Rollouts / envs are independent, so they are spread over the host

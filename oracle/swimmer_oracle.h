@@ -25,6 +25,8 @@ int swo_step(const swo_params *p, const double *state, const double *u,
 void swo_reset(const swo_params *p, double *state);
 int swo_rollout(const swo_params *p, int H, const double *policy, const double *mean,
                 const double *cov_diag, const double *state0, double *ret, double *traj);
+int swo_num_threads(void);
+void swo_set_num_threads(int t);
 int swo_step_batch(const swo_params *p, long n_env, const double *states,
                    const double *actions, double *next, double *rewards);
 int swo_rollout_batch(const swo_params *p, long n_roll, int H, const double *policies,

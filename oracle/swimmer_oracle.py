@@ -50,6 +50,9 @@ def _load():
         lib.swo_rollout.argtypes = [pp, ctypes.c_int, dp, dp, dp, dp, dp, dp]
         lib.swo_step_batch.argtypes = [pp, ctypes.c_long, dp, dp, dp, dp]
         lib.swo_rollout_batch.argtypes = [pp, ctypes.c_long, ctypes.c_int, dp, dp, dp, dp, dp]
+        lib.swo_num_threads.restype = ctypes.c_int
+        lib.swo_set_num_threads.argtypes = [ctypes.c_int]
+        lib.swo_set_num_threads.restype = None
         _lib = lib
     return _lib
 
@@ -69,10 +72,34 @@ def _check(rc):
         raise ValueError(f"oracle: bad arguments (rc={rc})")
 
 
+def cpu_share():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup
+    CPU quota (a GPU box exposes 256 logical CPUs but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0))
+    if os.environ.get("SWIMMER_CPU_THREADS"):
+        return max(1, int(os.environ["SWIMMER_CPU_THREADS"]))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:                                                                    # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def num_threads():
-    """Threads the *_batch functions use (OpenMP default: OMP_NUM_THREADS or all cores)."""
-    v = os.environ.get("OMP_NUM_THREADS")
-    return int(v) if v else len(os.sched_getaffinity(0))
+    """Threads the *_batch functions run on (asks the OpenMP runtime)."""
+    return int(_load().swo_num_threads())
+
+
+def set_num_threads(t):
+    _load().swo_set_num_threads(int(t))
 
 
 def accelerations(p, state, u):

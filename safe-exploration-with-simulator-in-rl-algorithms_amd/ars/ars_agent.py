@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from .. import kernels
-from .._lib import SwParams, SwimmerHipError
+from .._lib import SwParams, SwimmerHipError, require_gpu
 from .database import Database
 from .environment import Environment
 from .sharding import exchange, shard_bounds
@@ -40,6 +40,7 @@ class ARSAgent(object):
             raise NotImplementedError(
                 "safe exploration (ars_agent.py:144-157) gates every real rollout on a "
                 "simulator rollout, one at a time; it is outside the data-parallel path")
+        require_gpu()
         self.distributed = dist.is_available() and dist.is_initialized()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1

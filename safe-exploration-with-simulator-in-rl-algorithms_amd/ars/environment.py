@@ -11,7 +11,7 @@ import torch
 
 from .. import kernels
 from ..envs.swimmer import SwimmerEnv
-from .._lib import SwimmerHipError, STATUS_SINGULAR
+from .._lib import SwimmerHipError, STATUS_SINGULAR, require_gpu
 
 
 def inv_std_from_covariance(covariance, device):
@@ -34,6 +34,7 @@ class Environment(object):
 
     def select_action(self, policy, observation, covariance=None, mean=None):
         """Linear policy (V1: P s; V2: P diag(cov)^-1/2 (s - mean)), evaluated on the GPU."""
+        require_gpu()
         P = torch.as_tensor(np.asarray(policy, dtype=np.float64), device=self.device)
         obs = torch.as_tensor(np.asarray(observation, dtype=np.float64), device=self.device)
         if covariance is None or mean is None:
@@ -45,6 +46,7 @@ class Environment(object):
     def rollout_batch(self, policies, covariance=None, mean=None, H=None, want_traj=False,
                       state0=None):
         """policies [n_roll, m, d] -> (returns [n_roll] tensor, traj [H, d, n_roll] or None)."""
+        require_gpu()
         p = self.env._params()
         H = self.env_param.H if H is None else H
         pol = kernels._lib.dev_f64(policies, self.device)

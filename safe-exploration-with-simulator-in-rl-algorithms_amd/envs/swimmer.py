@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import kernels
-from .._lib import SwParams, STATUS_SINGULAR
+from .._lib import SwParams, STATUS_SINGULAR, require_gpu
 
 
 class Box(object):
@@ -45,6 +45,7 @@ class VecSwimmerEnv(object):
 
     def __init__(self, n_env, direction=(1.0, 0.0), n=3, max_u=5.0, l_i=1.0, k=10.0, m_i=1.0,
                  h=0.001, device="cuda:0", check_singular=False):
+        require_gpu()
         self.n_env = int(n_env)
         self.n, self.max_u, self.l_i, self.k, self.m_i, self.h = n, max_u, l_i, k, m_i, h
         self.direction = np.array(direction, dtype=np.float64)
@@ -147,6 +148,7 @@ class SwimmerEnv(object):
         return ob, reward, done, info
 
     def next_observation(self, torque, G_dot, theta, theta_dot):
+        require_gpu()
         if self._status is None:
             self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         nxt, _ = kernels.step(self._params(), self._soa(G_dot, theta, theta_dot),
@@ -156,6 +158,7 @@ class SwimmerEnv(object):
         return s[0:2].copy(), s[2::2].copy(), s[3::2].copy()
 
     def compute_accelerations(self, torque, G_dot, theta, theta_dot):
+        require_gpu()
         gdd, tdd = kernels.accelerations(self._params(), self._soa(G_dot, theta, theta_dot),
                                          self._act(torque))
         return gdd.reshape(-1).cpu().numpy(), tdd.reshape(-1).cpu().numpy()
