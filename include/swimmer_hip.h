@@ -59,6 +59,9 @@ extern "C" {
                                 finite: numpy.linalg.solve would raise LinAlgError
                                 (remy_swimmer_env.py:212) */
 #define SW_STATUS_NONFINITE 2 /* the new state contains inf / nan */
+#define SW_STATUS_RANGE 4     /* an angle reached |theta| >= 3e9 rad, outside the range of the
+                                 in-kernel sin/cos: outputs are NaN (a simulation that far gone
+                                 has ulp(theta) > 4e-7 rad and no meaning left) */
 
 /* Physical parameters of one swimmer model: SwimmerEnv.__init__ (remy_swimmer_env.py:16-39).
  * max_u is not here: the reference never enforces it (actions are not clipped). */

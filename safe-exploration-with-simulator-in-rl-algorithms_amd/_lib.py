@@ -19,6 +19,7 @@ ERR_NAMES = {0: "SW_OK", 1: "SW_ERR_NULL", 2: "SW_ERR_SEGMENTS", 3: "SW_ERR_SIZE
              4: "SW_ERR_PARAM", 5: "SW_ERR_LAUNCH"}
 STATUS_SINGULAR = 1
 STATUS_NONFINITE = 2
+STATUS_RANGE = 4
 
 
 class SwParams(ctypes.Structure):

@@ -66,36 +66,48 @@ template <int N> __host__ __device__ constexpr double Aw(int i1, int j1)
     return (2 * i1 - 1) / (double)N - (j1 < i1 ? 2.0 : (j1 == i1 ? 1.0 : 0.0));
 }
 
-// ---- sin and cos of one angle ----------------------------------------------------------
-// Cody-Waite reduction by pi/2 (two FMAs with the fl(pi/2) / tail split; the first FMA is
-// exact) + the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4] (coefficients:
-// Sun fdlibm k_sin.c / k_cos.c, public domain).  |error| < 1 ulp for |x| < 1e5; larger or
-// non-finite arguments take the (wave-uniformly never executed) library branch.
-__device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_out)
+// ---- sin and cos ----------------------------------------------------------------------
+// Cody-Waite reduction by pi/2 with three FMAs (pi/2 = H + M + L split into doubles; the
+// first FMA is exact, the other two round once each relative to the *reduced* argument, so
+// the result keeps ~1 ulp even next to multiples of pi/2) + the classic degree-13 /
+// degree-14 minimax kernels on [-pi/4, pi/4] (coefficients: Sun fdlibm k_sin.c / k_cos.c,
+// public domain).  Valid for |x| < kAngleLimit (quadrant index must fit 31 bits); callers
+// flag larger / non-finite angles with SW_STATUS_RANGE instead of computing garbage.
+//
+// A lone wave issues ONE instruction (of any kind) per ~4.4 cycles (scripts/ubench), so the
+// instruction count is the cost: there is no library fallback inside the hot loops (its
+// constants alone cost SGPR spills there), and fma(p, z, C) with a loop-invariant VGPR
+// constant C is requested in three-address form (hipcc otherwise emits
+// `v_mov_b64 tmp, C; v_fmac_f64 tmp, p, z`, two slots).
+constexpr double kAngleLimit = 3.0e9;  // < 2^31 * pi/2
+
+__device__ __forceinline__ double fma3(double a, double b, double c)
 {
-    if (__builtin_expect(!(__builtin_fabs(x) < 1.0e5), 0)) {
-        ::sincos(x, &s_out, &c_out);
-        return;
-    }
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_out)
+{
     const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: integer part lands in the low bits
     const double kd_m = __builtin_fma(x, 0.63661977236758134308, MAGIC);
     const double kd = kd_m - MAGIC;
     const uint32_t q = (uint32_t)__double_as_longlong(kd_m);
     double r = __builtin_fma(-kd, 1.5707963267948966, x);       // exact
     r = __builtin_fma(-kd, 6.123233995736766e-17, r);
+    r = __builtin_fma(-kd, -1.4973849048591698e-33, r);
     const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
-    double pc = -1.13596475577881948265e-11;
-    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    double ps = fma3(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+    ps = fma3(ps, z, 2.75573137070700676789e-06);
+    ps = fma3(ps, z, -1.98412698298579493134e-04);
+    ps = fma3(ps, z, 8.33333333332248946124e-03);
+    ps = fma3(ps, z, -1.66666666666666324348e-01);
+    double pc = fma3(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+    pc = fma3(pc, z, -2.75573143513906633035e-07);
+    pc = fma3(pc, z, 2.48015872894767294178e-05);
+    pc = fma3(pc, z, -1.38888888888741095749e-03);
+    pc = fma3(pc, z, 4.16666666666666019037e-02);
     const double sr = __builtin_fma(r * z, ps, r);
     const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
     // quadrant: q&1 swaps, q&2 negates sin, (q+1)&2 negates cos
@@ -106,6 +118,17 @@ __device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_ou
     const uint64_t cflip = (uint64_t)((q + 1u) & 2u) << 62;
     s_out = __longlong_as_double(__double_as_longlong(sv) ^ (long long)sflip);
     c_out = __longlong_as_double(__double_as_longlong(cv) ^ (long long)cflip);
+}
+
+// max(acc, |theta_i|): one v_max_f64 per angle; NaN angles are caught by the finiteness
+// check of the final state instead (v_max drops a NaN operand).
+template <int N>
+__device__ __forceinline__ double track_angle_range(double acc, const double (&th)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i)   // plain v_max_f64 (the builtin adds a canonicalising max)
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(acc) : "v"(acc), "v"(th[i]));
+    return acc;
 }
 
 // 1/x for a well-scaled positive x: hardware estimate + two Newton steps (full fp64).
@@ -209,7 +232,7 @@ __device__ __forceinline__ bool accelerations(const Consts &C, double gdx, doubl
 {
     double s[N], c[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) sincos_f64(th[i], s[i], c[i]);
+    for (int i = 0; i < N; ++i) sincos_fast(th[i], s[i], c[i]);
 
     double cc[N][N], ss[N][N];  // cc[i][j] = cos(th_i - th_j), ss[i][k] = sin(th_k - th_i)
 #pragma unroll

@@ -70,7 +70,13 @@ step_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
 #pragma unroll
     for (int i = 0; i < M; ++i) u[i] = act[(int64_t)i * n_env + e];
     double r;
+    const bool in_range = sw::track_angle_range<N>(0.0, th) < sw::kAngleLimit;
     const bool ok = sw::euler_step<N>(C, gdx, gdy, th, thd, u, r);
+    if (!in_range) {   // outside sincos_fast's range: NaN out, SW_STATUS_RANGE
+        gdx = gdy = r = __builtin_nan("");
+#pragma unroll
+        for (int i = 0; i < N; ++i) th[i] = thd[i] = __builtin_nan("");
+    }
     sout[e] = gdx;
     sout[n_env + e] = gdy;
     bool fin = isfinite(gdx) && isfinite(gdy);
@@ -81,7 +87,9 @@ step_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
         fin = fin && isfinite(th[i]) && isfinite(thd[i]);
     }
     if (reward) reward[e] = r;
-    if (status) status[e] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE);
+    if (status)
+        status[e] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE) |
+                    (in_range ? 0 : SW_STATUS_RANGE);
 }
 
 template <int N>
@@ -102,6 +110,11 @@ accel_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
 #pragma unroll
     for (int i = 0; i < M; ++i) u[i] = act[(int64_t)i * n_env + e];
     sw::accelerations<N>(C, gdx, gdy, th, thd, u, ax, ay, a);
+    if (!(sw::track_angle_range<N>(0.0, th) < sw::kAngleLimit)) {
+        ax = ay = __builtin_nan("");
+#pragma unroll
+        for (int i = 0; i < N; ++i) a[i] = __builtin_nan("");
+    }
     gdd[e] = ax;
     gdd[n_env + e] = ay;
 #pragma unroll
@@ -197,7 +210,9 @@ rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict
 
         double total = 0.0;
         bool ok = true;
+        double thmax = 0.0;  // largest |theta| fed to sincos_fast
         for (int32_t t = 0; t < H; ++t) {
+            thmax = sw::track_angle_range<N>(thmax, th);
             // action = W (s - mu)   (ars/environment.py:29 / :34); two partial sums
             double sm[D];
             sm[0] = gdx - mu[0];
@@ -246,11 +261,16 @@ rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict
                 }
             }
         }
-        returns[r] = total;
         bool fin = isfinite(gdx) && isfinite(gdy);
 #pragma unroll
         for (int i = 0; i < N; ++i) fin = fin && isfinite(th[i]) && isfinite(thd[i]);
-        if (status) status[r] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE);
+        const bool in_range = thmax < sw::kAngleLimit;
+        // an angle outside sincos_fast's range makes every later number meaningless: fail
+        // loudly (NaN return + status bit) instead of returning finite garbage
+        returns[r] = in_range ? total : __builtin_nan("");
+        if (status)
+            status[r] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE) |
+                        (in_range ? 0 : SW_STATUS_RANGE);
         if (final_state) {
             final_state[r] = gdx;
             final_state[n_roll + r] = gdy;

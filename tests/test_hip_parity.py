@@ -194,11 +194,22 @@ def test_edge_cases(sw):
     status = torch.zeros(64, dtype=torch.int32, device=dev)
     sw.kernels.step(p, st, torch.zeros((2, 64), dtype=torch.float64, device=dev), status=status)
     assert int(status[7]) != 0 and int(status.abs().sum()) == int(status[7])
-    # large angles take the library sincos branch and still agree with the oracle
-    big = np.array([[0.1, -0.2, 1.0e6 + 0.5, 0.3, -2.5e7, -0.1, 12345.678, 0.2]])
-    ref, _ = oracle.step_batch(oracle.OracleParams.make(3), big, np.array([[1.0, -1.0]]))
-    out, _ = sw.kernels.step(p, soa(big), soa(np.array([[1.0, -1.0]])))
-    assert np.abs(out.T.cpu().numpy() - ref).max() <= 1e-9   # |theta| ~ 1e7: ulp(theta) = 2e-9
+    # large angles: the 3-FMA Cody-Waite reduction still agrees with the oracle (libm)
+    big = np.array([[0.1, -0.2, 1.0e6 + 0.5, 0.3, -2.5e7, -0.1, 12345.678, 0.2],
+                    [0.1, -0.2, 2.9e9, 0.3, -1.0e9 - 0.25, -0.1, 7.0e8, 0.2]])
+    act = np.array([[1.0, -1.0], [0.5, 0.25]])
+    ref, _ = oracle.step_batch(oracle.OracleParams.make(3), big, act)
+    out, _ = sw.kernels.step(p, soa(big), soa(act))
+    rel = np.abs(out.T.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref))
+    assert rel.max() <= 1e-12
+    # beyond the supported range (|theta| >= 3e9): NaN out + SW_STATUS_RANGE, never garbage
+    far = big.copy()
+    far[1, 4] = 5.0e9
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    out, rew = sw.kernels.step(p, soa(far), soa(act), status=status)
+    assert int(status[0]) == 0 and int(status[1]) & 4
+    assert bool(torch.isnan(out[:, 1]).all()) and bool(torch.isnan(rew[1]))
+    assert bool(torch.isfinite(out[:, 0]).all())
 
 
 ARS_CASES = ["v2_n3_N4_H50", "v2_n3_N8_H50", "v2_n3_N4_H1000", "v2_n3_N6_H200_rw",
