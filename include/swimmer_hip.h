@@ -63,11 +63,16 @@ extern "C" {
                                  in-kernel sin/cos: outputs are NaN (a simulation that far gone
                                  has ulp(theta) > 4e-7 rad and no meaning left) */
 
+/* sw_params.flags: force one of the two rollout kernels (default: chosen from n and n_roll).
+ * Both compute the same rollouts; they differ in summation order only (a few ulp per step). */
+#define SW_FLAG_ROLLOUT_LANE 1 /* one rollout per lane (throughput form, any n) */
+#define SW_FLAG_ROLLOUT_QUAD 2 /* n = 3: one segment per lane, four lanes per rollout (latency form) */
+
 /* Physical parameters of one swimmer model: SwimmerEnv.__init__ (remy_swimmer_env.py:16-39).
  * max_u is not here: the reference never enforces it (actions are not clipped). */
 typedef struct sw_params {
     int32_t n;        /* segments */
-    int32_t flags;    /* reserved, must be 0 */
+    int32_t flags;    /* 0, or one SW_FLAG_ROLLOUT_* tuning flag */
     double l_i;       /* segment length */
     double m_i;       /* segment mass */
     double k;         /* viscous friction coefficient */
@@ -100,16 +105,17 @@ int sw_accel_f64(const sw_params *p, int64_t n_env, const double *state,
  *   returns       : [n_roll] sum of the H rewards
  *   traj          : NULL or [H][d][n_roll], every post-step state
  *   final_state   : NULL or [d][n_roll]
- *   moments       : NULL or [sw_moments_blocks(n_roll)][2d] per-workgroup partial sums
- *                   sum(s - c) and sum((s - c)^2) over all post-step states, c = reset state
+ *   moments       : NULL or [sw_moments_blocks(n_roll)][2d] partial sums, one row per 16
+ *                   consecutive rollouts, of sum(s - c) and sum((s - c)^2) over all their
+ *                   post-step states, c = reset state
  *   status        : NULL or [n_roll] */
 int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *policies,
                    const double *mean, const double *inv_std, const double *state0,
                    double *returns, double *traj, double *final_state, double *moments,
                    int32_t *status, void *stream);
 
-/* Number of per-workgroup partial-moment rows sw_rollout_f64 / sw_ars_rollouts_f64 write
- * for n_roll rollouts. */
+/* Number of partial-moment rows sw_rollout_f64 / sw_ars_rollouts_f64 write for n_roll
+ * rollouts (= ceil(n_roll / 16), whichever kernel runs). */
 int64_t sw_moments_blocks(int64_t n_roll);
 
 /* The ARS exploration batch: for directions i in [dir_begin, dir_begin + n_dir) run the two

@@ -20,6 +20,8 @@ ERR_NAMES = {0: "SW_OK", 1: "SW_ERR_NULL", 2: "SW_ERR_SEGMENTS", 3: "SW_ERR_SIZE
 STATUS_SINGULAR = 1
 STATUS_NONFINITE = 2
 STATUS_RANGE = 4
+FLAG_ROLLOUT_LANE = 1   # sw_params.flags: force the lane-per-rollout kernel
+FLAG_ROLLOUT_QUAD = 2   # force the n = 3 segment-per-lane (quad) kernel
 
 
 class SwParams(ctypes.Structure):
@@ -29,8 +31,8 @@ class SwParams(ctypes.Structure):
                 ("dir_x", ctypes.c_double), ("dir_y", ctypes.c_double)]
 
     @classmethod
-    def make(cls, n=3, l_i=1.0, m_i=1.0, k=10.0, h=1e-3, direction=(1.0, 0.0)):
-        return cls(int(n), 0, float(l_i), float(m_i), float(k), float(h),
+    def make(cls, n=3, l_i=1.0, m_i=1.0, k=10.0, h=1e-3, direction=(1.0, 0.0), flags=0):
+        return cls(int(n), int(flags), float(l_i), float(m_i), float(k), float(h),
                    float(direction[0]), float(direction[1]))
 
     @property
@@ -44,6 +46,14 @@ class SwParams(ctypes.Structure):
 
 class SwimmerHipError(RuntimeError):
     pass
+
+
+def kernel_flags(name):
+    """'auto' | 'lane' | 'quad' -> sw_params.flags value."""
+    try:
+        return {"auto": 0, "lane": FLAG_ROLLOUT_LANE, "quad": FLAG_ROLLOUT_QUAD}[name]
+    except KeyError:
+        raise SwimmerHipError(f"rollout kernel must be 'auto', 'lane' or 'quad', not {name!r}")
 
 
 _lib = None

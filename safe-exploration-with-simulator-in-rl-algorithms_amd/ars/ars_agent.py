@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from .. import kernels
-from .._lib import SwParams, SwimmerHipError, require_gpu
+from .._lib import SwParams, SwimmerHipError, kernel_flags, require_gpu
 from .database import Database
 from .environment import Environment
 from .sharding import exchange, shard_bounds
@@ -35,7 +35,7 @@ class ARSAgent(object):
     def __init__(self, real_env_param, agent_param, data_path=None, seed=None,
                  guess_param=None, approx_error=None, sim_thresh=None, *, device=None,
                  process_group=None, record_trajectories=False, full_covariance=True,
-                 top_b=0):
+                 top_b=0, rollout_kernel="auto"):
         if agent_param.safe:
             raise NotImplementedError(
                 "safe exploration (ars_agent.py:144-157) gates every real rollout on a "
@@ -61,7 +61,8 @@ class ARSAgent(object):
         self.m, self.d = n - 1, 2 * n + 2
         # direction / max_u keep the env defaults, as in the reference (environment.py:15-17)
         self.params = SwParams.make(n, real_env_param.l_i, real_env_param.m_i,
-                                    real_env_param.k, real_env_param.h, (1.0, 0.0))
+                                    real_env_param.k, real_env_param.h, (1.0, 0.0),
+                                    flags=kernel_flags(rollout_kernel))
         if agent_param.initial_w == 'Zero':
             policy = np.zeros((self.m, self.d))
         else:

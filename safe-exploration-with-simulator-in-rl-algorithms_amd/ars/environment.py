@@ -11,7 +11,7 @@ import torch
 
 from .. import kernels
 from ..envs.swimmer import SwimmerEnv
-from .._lib import SwimmerHipError, STATUS_SINGULAR, require_gpu
+from .._lib import SwimmerHipError, STATUS_SINGULAR, kernel_flags, require_gpu
 
 
 def inv_std_from_covariance(covariance, device):
@@ -24,8 +24,9 @@ def inv_std_from_covariance(covariance, device):
 
 class Environment(object):
 
-    def __init__(self, env_param, device="cuda:0"):
+    def __init__(self, env_param, device="cuda:0", rollout_kernel="auto"):
         self.env_param = env_param
+        self.kernel_flags = kernel_flags(rollout_kernel)
         self.device = torch.device(device)
         # direction and max_u keep their defaults, as in the reference (:15-17)
         self.env = SwimmerEnv(envName=env_param.name, n=env_param.n, l_i=env_param.l_i,
@@ -48,6 +49,7 @@ class Environment(object):
         """policies [n_roll, m, d] -> (returns [n_roll] tensor, traj [H, d, n_roll] or None)."""
         require_gpu()
         p = self.env._params()
+        p.flags = self.kernel_flags
         H = self.env_param.H if H is None else H
         pol = kernels._lib.dev_f64(policies, self.device)
         n_roll = pol.shape[0]

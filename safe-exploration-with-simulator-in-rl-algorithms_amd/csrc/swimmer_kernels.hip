@@ -17,12 +17,15 @@
 
 #include "../../include/swimmer_hip.h"
 #include "swimmer_device.h"
+#include "swimmer_quad3.h"
 
 namespace {
 
 constexpr int kWave = 64;
 constexpr int kStepBlock = 256;
 constexpr int kRollBlock = 64;   // one wave per workgroup: every wave gets a SIMD to itself
+constexpr int kMomGroup = 16;    // rollouts per V2 moment row (same partition in every kernel)
+constexpr int64_t kQuadMaxRollouts = 16384;  // above this every SIMD already has a wave
 constexpr int kUpdBlock = 256;
 constexpr double kHalfPi = 1.57079632679489661923;  // math.pi / 2 (remy_swimmer_env.py:65)
 
@@ -44,6 +47,7 @@ int check_params(const sw_params *p)
 {
     if (!p) return SW_ERR_NULL;
     if (p->n < 2 || p->n > SW_MAX_SEGMENTS) return SW_ERR_SEGMENTS;
+    if (p->flags & ~(SW_FLAG_ROLLOUT_LANE | SW_FLAG_ROLLOUT_QUAD)) return SW_ERR_PARAM;
     if (!(p->l_i > 0.0) || !(p->m_i > 0.0) || !isfinite(p->l_i) || !isfinite(p->m_i) ||
         !isfinite(p->k) || !isfinite(p->h) || !isfinite(p->dir_x) || !isfinite(p->dir_y))
         return SW_ERR_PARAM;
@@ -283,18 +287,153 @@ rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict
     }
 
     if (moments) {
-        // fixed-order butterfly over the wave (deterministic), lane 0 writes the row
+        // fixed-order butterfly over each group of 16 lanes (deterministic); one row of
+        // partial sums per 16 rollouts, the same partition the quad kernel produces
+        const int64_t n_rows = (n_roll + kMomGroup - 1) / kMomGroup;
+        const int64_t row = (int64_t)blockIdx.x * (kRollBlock / kMomGroup) + threadIdx.x / kMomGroup;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             double a = m1[j], b = m2[j];
 #pragma unroll
-            for (int off = kWave / 2; off > 0; off >>= 1) {
-                a += __shfl_down(a, off, kWave);
-                b += __shfl_down(b, off, kWave);
+            for (int off = kMomGroup / 2; off > 0; off >>= 1) {
+                a += __shfl_down(a, off, kMomGroup);
+                b += __shfl_down(b, off, kMomGroup);
             }
-            if (threadIdx.x == 0) {
-                moments[(int64_t)blockIdx.x * (2 * D) + j] = a;
-                moments[(int64_t)blockIdx.x * (2 * D) + D + j] = b;
+            if (threadIdx.x % kMomGroup == 0 && row < n_rows) {
+                moments[row * (2 * D) + j] = a;
+                moments[row * (2 * D) + D + j] = b;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// n = 3, one segment per lane (swimmer_quad3.h): 16 rollouts per 64-thread workgroup.
+template <bool ARS>
+__global__ void __launch_bounds__(kRollBlock)
+rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict__ policies,
+                     const double *__restrict__ deltas, int64_t dir_begin, double nu,
+                     const double *__restrict__ mean, const double *__restrict__ inv_std,
+                     const double *__restrict__ state0, double *__restrict__ returns,
+                     double *__restrict__ traj, double *__restrict__ final_state,
+                     double *__restrict__ moments, int32_t *__restrict__ status)
+{
+    constexpr int D = 8, M = 2;
+    const int lane = threadIdx.x;
+    const int q = lane & 3;
+    const int seg = (q == 3) ? 0 : q;              // lane 3 mirrors lane 0
+    const int64_t r_raw = (int64_t)blockIdx.x * kMomGroup + (lane >> 2);
+    const bool valid = r_raw < n_roll;
+    const int64_t r = valid ? r_raw : n_roll - 1;  // surplus quads recompute the last rollout
+    const sw::Quad3Lane L = sw::quad3_lane(seg);
+    const int cth = 2 + 2 * seg, cthd = 3 + 2 * seg;
+
+    // ---- this lane's four policy columns: Gdot (segment 0 only), theta_i, thetadot_i ----
+    double Wg0[M], Wg1[M], Wth[M], Wthd[M];
+    {
+        const double *pl = ARS ? policies : policies + r * (M * D);
+        const double *dl = ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr;
+        const double sgn = (r & 1) ? -1.0 : 1.0;
+        auto entry = [&](int a, int col) {
+            double w = pl[a * D + col];
+            if (ARS) w = __dadd_rn(w, sgn * __dmul_rn(nu, dl[a * D + col]));   // ars_agent.py:141-142
+            if (inv_std) w = __dmul_rn(w, inv_std[col]);                       // environment.py:32-33
+            return w;
+        };
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            Wg0[a] = (seg == 0) ? entry(a, 0) : 0.0;
+            Wg1[a] = (seg == 0) ? entry(a, 1) : 0.0;
+            Wth[a] = entry(a, cth);
+            Wthd[a] = entry(a, cthd);
+        }
+    }
+    const double mu0 = mean ? mean[0] : 0.0, mu1 = mean ? mean[1] : 0.0;
+    const double muth = mean ? mean[cth] : 0.0, muthd = mean ? mean[cthd] : 0.0;
+
+    // ---- start state ----
+    double gdx = 0.0, gdy = 0.0, th = kHalfPi, thd = 0.0;
+    if (state0) {
+        gdx = state0[r];
+        gdy = state0[n_roll + r];
+        th = state0[(int64_t)cth * n_roll + r];
+        thd = state0[(int64_t)cthd * n_roll + r];
+    }
+    // byte offsets of this lane's three trajectory cells inside one step's [D][n_roll] slab
+    const uint32_t off_th = (uint32_t)(((int64_t)cth * n_roll + r) * 8);
+    const uint32_t off_thd = (uint32_t)(((int64_t)cthd * n_roll + r) * 8);
+    const uint32_t off_g = (uint32_t)(((int64_t)(seg == 0 ? 0 : 1) * n_roll + r) * 8);
+    const int64_t slab = (int64_t)D * n_roll * 8;
+
+    double total = 0.0, thmax = 0.0, detmin = 1.0;
+    double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
+    for (int32_t t = 0; t < H; ++t) {
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
+        // partial action of this lane's columns, then the sum over the three segments
+        const double e0 = gdx - mu0, e1 = gdy - mu1, e2 = th - muth, e3 = thd - muthd;
+        double p0 = __builtin_fma(Wthd[0], e3, __builtin_fma(Wth[0], e2,
+                    __builtin_fma(Wg1[0], e1, Wg0[0] * e0)));
+        double p1 = __builtin_fma(Wthd[1], e3, __builtin_fma(Wth[1], e2,
+                    __builtin_fma(Wg1[1], e1, Wg0[1] * e0)));
+        const double u0 = (p0 + sw::dpp_f64<sw::kDppNext1>(p0)) + sw::dpp_f64<sw::kDppNext2>(p0);
+        const double u1 = (p1 + sw::dpp_f64<sw::kDppNext1>(p1)) + sw::dpp_f64<sw::kDppNext2>(p1);
+        const double det = sw::quad3_step(C, L, gdx, gdy, th, thd, u0, u1);
+        asm("v_min_f64 %0, %1, %2" : "=v"(detmin) : "v"(detmin), "v"(det));
+        total += __builtin_fma(gdx, C.dirx, gdy * C.diry);
+        const double gsel = __builtin_fma(L.gx, gdx, L.gy * gdy);
+        if (traj) {
+            char *tb = (char *)traj + (int64_t)t * slab;
+            *(double *)(tb + off_th) = th;
+            *(double *)(tb + off_thd) = thd;
+            *(double *)(tb + off_g) = gsel;
+        }
+        if (moments) {
+            const double a = th - kHalfPi;
+            m1th += a;
+            m2th = __builtin_fma(a, a, m2th);
+            m1thd += thd;
+            m2thd = __builtin_fma(thd, thd, m2thd);
+            m1g += gsel;
+            m2g = __builtin_fma(gsel, gsel, m2g);
+        }
+    }
+
+    // ---- per-rollout outputs (quad lanes 0..2 hold the state; lane 0 the return) ----
+    int code = ((detmin > 0.0) ? 0 : SW_STATUS_SINGULAR) |
+               ((isfinite(th) && isfinite(thd) && isfinite(gdx) && isfinite(gdy)) ? 0 : SW_STATUS_NONFINITE) |
+               ((thmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
+    code |= __builtin_amdgcn_mov_dpp(code, sw::kDppNext1, 0xf, 0xf, true) |
+            __builtin_amdgcn_mov_dpp(code, sw::kDppNext2, 0xf, 0xf, true);
+    if (valid && q == 0) {
+        returns[r] = (code & SW_STATUS_RANGE) ? __builtin_nan("") : total;
+        if (status) status[r] = code;
+    }
+    if (final_state && valid && q < 3) {
+        final_state[(int64_t)cth * n_roll + r] = th;
+        final_state[(int64_t)cthd * n_roll + r] = thd;
+        if (q < 2) final_state[(int64_t)q * n_roll + r] = (q == 0) ? gdx : gdy;
+    }
+    if (moments) {
+        if (!valid) m1th = m2th = m1thd = m2thd = m1g = m2g = 0.0;
+        // sum over the 16 rollouts of the wave, per segment lane: xor-butterfly over lane>>2
+#pragma unroll
+        for (int off = 4; off < kWave; off <<= 1) {
+            m1th += __shfl_xor(m1th, off, kWave);
+            m2th += __shfl_xor(m2th, off, kWave);
+            m1thd += __shfl_xor(m1thd, off, kWave);
+            m2thd += __shfl_xor(m2thd, off, kWave);
+            m1g += __shfl_xor(m1g, off, kWave);
+            m2g += __shfl_xor(m2g, off, kWave);
+        }
+        if (lane < 3) {
+            double *row = moments + (int64_t)blockIdx.x * (2 * D);
+            row[cth] = m1th;
+            row[cthd] = m1thd;
+            row[D + cth] = m2th;
+            row[D + cthd] = m2thd;
+            if (lane < 2) {
+                row[lane] = m1g;
+                row[D + lane] = m2g;
             }
         }
     }
@@ -474,6 +613,16 @@ traj_moments_kernel(int64_t n_roll, int32_t H, const double *__restrict__ traj,
     default: return SW_ERR_SEGMENTS;           \
     }
 
+// Kernel choice for rollouts: the quad (segment-per-lane) kernel while it still finds idle
+// SIMDs, the lane-per-rollout kernel beyond; sw_params.flags can force either.
+bool use_quad3(const sw_params *p, int64_t n_roll)
+{
+    if (p->n != 3) return false;
+    if (p->flags & SW_FLAG_ROLLOUT_LANE) return false;
+    if (p->flags & SW_FLAG_ROLLOUT_QUAD) return n_roll < (int64_t)1 << 25;  // 32-bit cell offsets
+    return n_roll <= kQuadMaxRollouts;
+}
+
 int launch_status()
 {
     return hipGetLastError() == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
@@ -502,7 +651,7 @@ const char *sw_strerror(int code)
 
 int64_t sw_moments_blocks(int64_t n_roll)
 {
-    return n_roll <= 0 ? 0 : (n_roll + kRollBlock - 1) / kRollBlock;
+    return n_roll <= 0 ? 0 : (n_roll + kMomGroup - 1) / kMomGroup;
 }
 
 int sw_reset_f64(const sw_params *p, int64_t n_env, double *state, void *stream)
@@ -560,7 +709,15 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
     if (!policies || !returns) return SW_ERR_NULL;
     if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
-    const unsigned grid = (unsigned)sw_moments_blocks(n_roll);
+    if (use_quad3(p, n_roll)) {
+        const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        hipLaunchKernelGGL((rollout_quad3_kernel<false>), dim3(grid), dim3(kRollBlock), 0,
+                           (hipStream_t)stream, C, n_roll, H, policies, (const double *)nullptr,
+                           (int64_t)0, 0.0, mean, inv_std, state0, returns, traj, final_state,
+                           moments, status);
+        return launch_status();
+    }
+    const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
     SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, false>), dim3(grid), dim3(kRollBlock),
                                            0, (hipStream_t)stream, C, n_roll, H, policies,
                                            (const double *)nullptr, (int64_t)0, 0.0, mean, inv_std,
@@ -581,7 +738,15 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
     if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
     const int64_t n_roll = 2 * n_dir;
-    const unsigned grid = (unsigned)sw_moments_blocks(n_roll);
+    if (use_quad3(p, n_roll)) {
+        const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        hipLaunchKernelGGL((rollout_quad3_kernel<true>), dim3(grid), dim3(kRollBlock), 0,
+                           (hipStream_t)stream, C, n_roll, H, policy, deltas, dir_begin, nu, mean,
+                           inv_std, (const double *)nullptr, returns, traj, (double *)nullptr,
+                           moments, status);
+        return launch_status();
+    }
+    const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
     SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, true>), dim3(grid), dim3(kRollBlock),
                                            0, (hipStream_t)stream, C, n_roll, H, policy, deltas,
                                            dir_begin, nu, mean, inv_std, (const double *)nullptr,

@@ -1,0 +1,143 @@
+// swimmer_quad3.h -- latency-optimised rollout kernel for the 3-segment swimmer:
+// ONE SEGMENT PER LANE, four lanes (a DPP quad) per rollout, 16 rollouts per wave.
+//
+// Why: the BASELINE configs run 1024-4096 rollouts per GPU, far fewer than the chip's
+// 1024 SIMDs x 64 lanes.  With one rollout per lane (rollout_kernel) a batch of 1024
+// rollouts occupies 16 SIMDs and its speed is the length of one lane's instruction stream
+// (~310 instructions per step, one instruction per ~4.4 cycles for a lone wave,
+// scripts/ubench).  Spreading a rollout over the lanes of a quad cuts that stream to ~170
+// instructions per step at 4x the (idle anyway) SIMD count:
+//
+//   lane q = 0,1,2 of a quad owns segment q: its angle, angular velocity, sin/cos, its row
+//   of the 3x3 joint-acceleration system, its two columns of the linear policy and its V2
+//   moment sums; lane 3 mirrors lane 0 bit for bit (same inputs, same permutation sources),
+//   so whatever it stores duplicates lane 0's stores.
+//   Neighbour data moves with DPP quad_perm moves (no LDS, no memory, two 32-bit moves per
+//   double): next1 = segment (q+1)%3, next2 = segment (q+2)%3.
+//   Every lane solves the SAME symmetric 3x3 system in its own rotated order
+//   (own, next1, next2) and keeps only its own component (closed-form cofactor row, one
+//   reciprocal), so no lane-dependent code is needed: all lane dependence sits in a few
+//   per-lane constants (chain weights for its rotation) loaded in the prologue.
+//   Gdot is replicated per lane and re-synchronised from lane 0 after every step, so the
+//   state of a rollout is well defined: Gdot from lane 0, (theta_i, thetadot_i) from lane i.
+//
+// Same equations as swimmer_device.h (see the derivation there); the per-step arithmetic
+// differs from rollout_kernel only in summation order (<= a few ulp per step).
+#pragma once
+
+#include "swimmer_device.h"
+
+namespace sw {
+
+// quad_perm control words: lane j of a quad reads lane perm[j]
+constexpr int kDppNext1 = 1 | (2 << 2) | (0 << 4) | (1 << 6);  // [1,2,0,1]
+constexpr int kDppNext2 = 2 | (0 << 2) | (1 << 4) | (2 << 6);  // [2,0,1,2]
+constexpr int kDppLane0 = 0;                                   // [0,0,0,0]
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // every lane is active and every source lane exists, so the "old" value is never used:
+    // mov_dpp (undefined old) saves the copy update_dpp's tied operand would need
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Per-lane constants for segment i of the 3-segment chain in the rotated order
+// (i, i1 = i+1 mod 3, i2 = i+2 mod 3).
+struct Quad3Lane {
+    double vw0, vw1, vw2;   // vel_w(i,i), vel_w(i,i1), vel_w(i,i2)
+    double a0, a1, a2;      // Aw(i,i), Aw(i,i1), Aw(i,i2)
+    double t1, t2, t12;     // -6 T(i,i1), -6 T(i,i2), -6 T(i1,i2)
+    double d0, d12, d1, d2; // diagonal of Q in rotated order, d12 = d1*d2
+    double ta, tb;          // joint-torque balance u_{i-1} - u_i = ta*u0 + tb*u1
+    double gx, gy;          // Gdot component this lane records: x on segment 0, y on 1 and 2
+};
+
+__device__ __forceinline__ Quad3Lane quad3_lane(int seg)
+{
+    Quad3Lane L;
+    auto pick = [&](double v0, double v1, double v2) { return seg == 0 ? v0 : (seg == 1 ? v1 : v2); };
+    // 1-based indices in the weight functions
+    L.vw0 = pick(vel_w<3>(1, 1), vel_w<3>(2, 2), vel_w<3>(3, 3));
+    L.vw1 = pick(vel_w<3>(1, 2), vel_w<3>(2, 3), vel_w<3>(3, 1));
+    L.vw2 = pick(vel_w<3>(1, 3), vel_w<3>(2, 1), vel_w<3>(3, 2));
+    L.a0 = pick(Aw<3>(1, 1), Aw<3>(2, 2), Aw<3>(3, 3));
+    L.a1 = pick(Aw<3>(1, 2), Aw<3>(2, 3), Aw<3>(3, 1));
+    L.a2 = pick(Aw<3>(1, 3), Aw<3>(2, 1), Aw<3>(3, 2));
+    L.t1 = pick(-6.0 * Tw<3>(1, 2), -6.0 * Tw<3>(2, 3), -6.0 * Tw<3>(3, 1));
+    L.t2 = pick(-6.0 * Tw<3>(1, 3), -6.0 * Tw<3>(2, 1), -6.0 * Tw<3>(3, 2));
+    L.t12 = pick(-6.0 * Tw<3>(2, 3), -6.0 * Tw<3>(3, 1), -6.0 * Tw<3>(1, 2));
+    constexpr double D1 = -6.0 * Tw<3>(1, 1) + 1.0, D2 = -6.0 * Tw<3>(2, 2) + 1.0,
+                     D3 = -6.0 * Tw<3>(3, 3) + 1.0;
+    L.d0 = pick(D1, D2, D3);
+    L.d1 = pick(D2, D3, D1);
+    L.d2 = pick(D3, D1, D2);
+    L.d12 = L.d1 * L.d2;
+    L.ta = pick(-1.0, 1.0, 0.0);
+    L.tb = pick(0.0, -1.0, 1.0);
+    L.gx = pick(1.0, 0.0, 0.0);
+    L.gy = pick(0.0, 1.0, 1.0);
+    return L;
+}
+
+// One explicit-Euler step of one rollout spread over a quad.  On entry/exit: gdx, gdy
+// replicated, th/thd own segment.  u0, u1: joint torques (identical on all lanes up to
+// summation order).  Returns det of the (rotated) system for the singularity check.
+__device__ __forceinline__ double quad3_step(const Consts &C, const Quad3Lane &L, double &gdx,
+                                             double &gdy, double &th, double &thd, double u0,
+                                             double u1)
+{
+    double s, c;
+    sincos_fast(th, s, c);
+    // neighbours' sin, cos, angular velocity
+    const double s1 = dpp_f64<kDppNext1>(s), c1 = dpp_f64<kDppNext1>(c);
+    const double s2 = dpp_f64<kDppNext2>(s), c2 = dpp_f64<kDppNext2>(c);
+    const double w1 = dpp_f64<kDppNext1>(thd), w2 = dpp_f64<kDppNext2>(thd);
+    // cos(th_i - th_k), sin(th_k - th_i)
+    const double cc1 = __builtin_fma(c, c1, s * s1), cc2 = __builtin_fma(c, c2, s * s2);
+    const double cc12 = __builtin_fma(c1, c2, s1 * s2);
+    const double ss1 = __builtin_fma(c, s1, -s * c1), ss2 = __builtin_fma(c, s2, -s * c2);
+    // normal velocity of this segment's centre
+    double g = __builtin_fma(gdy, c, -gdx * s);
+    g = __builtin_fma(L.vw0 * C.l, thd, g);
+    g = __builtin_fma((L.vw1 * C.l) * cc1, w1, g);
+    g = __builtin_fma((L.vw2 * C.l) * cc2, w2, g);
+    const double g1 = dpp_f64<kDppNext1>(g), g2 = dpp_f64<kDppNext2>(g);
+    // barycentre acceleration (rotated summation order; re-synchronised by the caller)
+    const double sx = __builtin_fma(g2, s2, __builtin_fma(g1, s1, g * s));
+    const double sy = __builtin_fma(g2, c2, __builtin_fma(g1, c1, g * c));
+    const double gddx = C.kl_nm * sx, gddy = -C.kl_nm * sy;
+    // this segment's row of Q thdd = r
+    double cent = (L.t1 * (w1 * w1)) * ss1;
+    cent = __builtin_fma(L.t2 * (w2 * w2), ss2, cent);
+    double fric = L.a0 * g;
+    fric = __builtin_fma(L.a1 * cc1, g1, fric);
+    fric = __builtin_fma(L.a2 * cc2, g2, fric);
+    const double tq = __builtin_fma(L.ta, u0, L.tb * u1);
+    double r0 = __builtin_fma(-C.six_k_m, fric, cent);
+    r0 = __builtin_fma(C.kl_m, thd, r0);
+    r0 = __builtin_fma(C.c12, tq, r0);
+    const double r1 = dpp_f64<kDppNext1>(r0), r2 = dpp_f64<kDppNext2>(r0);
+    // first row of the adjugate of [[d0,a,b],[a,d1,e],[b,e,d2]]
+    const double a = L.t1 * cc1, b = L.t2 * cc2, e = L.t12 * cc12;
+    const double c00 = __builtin_fma(-e, e, L.d12);
+    const double c01 = __builtin_fma(b, e, -a * L.d2);
+    const double c02 = __builtin_fma(a, e, -b * L.d1);
+    const double det = __builtin_fma(L.d0, c00, __builtin_fma(a, c01, b * c02));
+    const double num = __builtin_fma(c00, r0, __builtin_fma(c01, r1, c02 * r2));
+    const double tdd = num * rcp_f64(det);
+    // explicit Euler (remy_swimmer_env.py:87-91)
+    gdx = __builtin_fma(C.h, gddx, gdx);
+    gdy = __builtin_fma(C.h, gddy, gdy);
+    th = __builtin_fma(C.h, thd, th);
+    thd = __builtin_fma(C.h, tdd, thd);
+    // one authoritative Gdot per rollout: lane 0's
+    gdx = dpp_f64<kDppLane0>(gdx);
+    gdy = dpp_f64<kDppLane0>(gdy);
+    return det;
+}
+
+}  // namespace sw

@@ -107,15 +107,19 @@ def _traj_keys(t):
     return [x[:-len("_return")] for x in t.files if x.endswith("_return")]
 
 
-def test_rollouts_vs_reference_golden(sw, golden):
+@pytest.mark.parametrize("kernel", ["lane", "quad"])
+def test_rollouts_vs_reference_golden(sw, golden, kernel):
+    """Both rollout kernels (one rollout per lane / n = 3: one segment per lane)."""
     t = golden.trajectories
     worst = 0.0
     for key in _traj_keys(t):
         n = int(key.split("_n")[1][0])
+        if kernel == "quad" and n != 3:
+            continue
         l, m, k, h = PARAM_SETS[key.split("_")[2]]
         H = t[key + "_traj"].shape[0]
         ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)
-        env = sw.Environment(ep)
+        env = sw.Environment(ep, rollout_kernel=kernel)
         mean = t[key + "_mean"] if key + "_mean" in t.files else None
         cov = t[key + "_cov"] if key + "_cov" in t.files else None
         ret, states = env.rollout(t[key + "_policy"], covariance=cov, mean=mean)
@@ -124,14 +128,18 @@ def test_rollouts_vs_reference_golden(sw, golden):
         worst = max(worst, err)
         assert err <= TRAJ_TOL, key
         assert abs(ret - float(t[key + "_return"])) <= 1e-9 * max(1.0, abs(float(t[key + "_return"]))), key
-    print(f"worst trajectory deviation over {len(_traj_keys(t))} reference rollouts: {worst:.3e}")
+    print(f"[{kernel}] worst trajectory deviation over the reference rollouts: {worst:.3e}")
 
 
-def test_rollout_batch_vs_oracle_and_moments(sw):
+@pytest.mark.parametrize("kernel", ["lane", "quad"])
+def test_rollout_batch_vs_oracle_and_moments(sw, kernel):
     """Many different policies at once (ragged last wave), V2 whitening, start states,
     final states and the fused moment sums."""
     rng = np.random.default_rng(5)
-    for n, R, H in ((3, 200, 300), (6, 70, 120), (2, 1, 50), (4, 65, 64)):
+    cases = ((3, 200, 300), (6, 70, 120), (2, 1, 50), (4, 65, 64), (3, 1, 40), (3, 17, 33))
+    for n, R, H in cases:
+        if kernel == "quad" and n != 3:
+            continue
         d, m = 2 * n + 2, n - 1
         l, mm, k, h = PARAM_SETS["realworld"]
         pol = 0.1 * rng.uniform(-1, 1, (R, m, d))
@@ -140,7 +148,7 @@ def test_rollout_batch_vs_oracle_and_moments(sw):
         var = rng.uniform(0.3, 2.0, d)
         op = oracle.OracleParams.make(n, l, mm, k, h)
         ref_ret, ref_traj = oracle.rollout_batch(op, H, pol, mean, var, want_traj=True)
-        p = sw.SwParams.make(n, l, mm, k, h)
+        p = sw.SwParams.make(n, l, mm, k, h, flags=sw._lib.kernel_flags(kernel))
         dev = "cuda:0"
         traj = torch.empty((H, d, R), dtype=torch.float64, device=dev)
         fin = torch.empty((d, R), dtype=torch.float64, device=dev)
@@ -221,22 +229,25 @@ def cov_close(c, ref, rel):
     return bool((np.abs(c - ref) <= rel * np.outer(sd, sd)).all())
 
 
+@pytest.mark.parametrize("kernel", ["lane", "quad"])
 @pytest.mark.parametrize("tag", ARS_CASES)
-def test_ars_iterations_vs_reference_golden(sw, golden, tag):
+def test_ars_iterations_vs_reference_golden(sw, golden, tag, kernel):
     a = golden.ars
+    if kernel == "quad" and "_n3_" not in tag:
+        pytest.skip("the quad kernel is the 3-segment specialisation")
     n, V1, N, b, H, seed, iters = [int(x) for x in a[tag + "_cfg"]]
     l, m, k, h, alpha, nu = [float(x) for x in a[tag + "_phys"]]
     ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)
     ap = sw.ARSParam("Test", V1=bool(V1), n_iter=iters, H=H, N=N, b=b, alpha=alpha, nu=nu,
                      safe=False, threshold=0, initial_w="Zero")
-    agent = sw.ARSAgent(ep, ap, seed=seed)
+    agent = sw.ARSAgent(ep, ap, seed=seed, rollout_kernel=kernel)
     for it in range(iters):
         r = np.array(agent.runOneIteration())
         ref = a[tag + "_rewards"][it]
         assert r.shape == (2 * N,)
         assert np.abs(r - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (tag, it)
         perr = np.abs(agent.policy - a[tag + "_policies"][it]).max()
-        print(f"{tag} it{it}: max|dP| = {perr:.3e}, max|dR| = {np.abs(r - ref).max():.3e}")
+        print(f"[{kernel}] {tag} it{it}: max|dP| = {perr:.3e}, max|dR| = {np.abs(r - ref).max():.3e}")
         assert perr <= (1e-6 if H <= 50 else 1e-9), (tag, it)
         assert perr <= CONTRACT_TOL
         if not V1:

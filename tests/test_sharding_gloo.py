@@ -30,10 +30,10 @@ def _worker(rank, world, port, n_dir, w, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lo, hi, chunk = shard_bounds(n_dir, rank, world)
-        rows_chunk = -(-2 * chunk // 64)
+        rows_chunk = -(-2 * chunk // 16)
         rl = torch.tensor([_fake_return(i, s) for i in range(lo, hi) for s in (1, -1)],
                           dtype=torch.float64)
-        rows_local = -(-2 * (hi - lo) // 64) if hi > lo else 0
+        rows_local = -(-2 * (hi - lo) // 16) if hi > lo else 0
         ml = torch.full((rows_local, w), float(rank + 1), dtype=torch.float64)
         ra, ma = exchange(rl, ml, n_dir, world, None, rows_chunk)
         expect = torch.tensor([_fake_return(i, s) for i in range(n_dir) for s in (1, -1)],
@@ -41,7 +41,7 @@ def _worker(rank, world, port, n_dir, w, out):
         ok = torch.equal(ra, expect) and ma.shape == (world * rows_chunk, w)
         # the update sums the rows: every rank must see the same total
         tot = ma.sum(0)
-        allr = [-(-2 * (shard_bounds(n_dir, r, world)[1] - shard_bounds(n_dir, r, world)[0]) // 64)
+        allr = [-(-2 * (shard_bounds(n_dir, r, world)[1] - shard_bounds(n_dir, r, world)[0]) // 16)
                 * (r + 1.0) for r in range(world)]
         ok = ok and bool(torch.all(tot == sum(allr)))
         out.put((rank, bool(ok)))
