@@ -53,6 +53,15 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel, n, directions, H):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None when
+    the measured workload is not the one being benchmarked."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    if not os.path.exists(path) or (n, directions, H) != (3, 512, 1000):
+        return None
+    return json.load(open(path)).get(kernel, {}).get("traffic_bytes")
+
+
 def cpu_baseline(n, H, directions, seconds):
     """Time the oracle (C port of the reference step/rollout, OpenMP) on whole rollout
     batches of the benchmark's shape until `seconds` have elapsed."""
@@ -142,13 +151,14 @@ def main():
     for _ in range(args.warmup):
         agent.run_iteration_async()
     sync()
-    agent.kernel_events = []
+    agent._pipe.timing(True)   # HIP events around every rollout launch, on its stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         agent.run_iteration_async()
     sync()
     dt = time.perf_counter() - t0
-    events, agent.kernel_events = agent.kernel_events, None
+    kern_ms, kern_launches = agent._pipe.rollout_ms()
+    agent._pipe.timing(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,7 +171,7 @@ def main():
         steps_per_iter = 2 * N * H
         value = steps_per_iter * args.steps / dt
         d = 2 * n + 2
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        assert kern_launches == args.steps
         local_steps = 2 * agent.n_local * H
         # algorithmic HBM bytes of one rollout launch: every post-step state is
         # materialised (8 d bytes per env-step, as the reference does, ars/environment.py:53)
@@ -182,8 +192,12 @@ def main():
                        "parallelism": f"directions sharded over {world} GPU(s), "
                                       "1 all-gather/iteration"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "rollout_kernel<3,true>" if n == 3 else f"rollout_kernel<{n},true>",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic("rollout_quad3_kernel<true,true,true>", n,
+                                                args.directions, H),
+                         "algorithmic_bytes": alg_bytes,
+                         "kernel": ("rollout_quad3_kernel<true,true,true>" if n == 3
+                                    else f"rollout_kernel<{n},true>"),
                          "kernel_ms": kern_ms,
                          "note": "the fused rollout is fp64-VALU-latency bound by construction "
                                  "(state, policy and sums stay in registers); HBM is the "

@@ -156,6 +156,50 @@ int sw_ars_update_f64(const sw_params *p, int64_t n_dir, const double *returns,
 int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
                         double *acc, void *stream);
 
+
+/* ---- ARS iteration pipeline (host-side enqueue logic in native code) ------------------
+ * Replaces the serial body of ARSAgent.runOneIteration (ars/ars_agent.py:137-182) with a
+ * three-stream schedule over a ring of SW_PIPELINE_SLOTS buffer sets.  A pipeline owns two
+ * extra HIP streams (copy, cov) and the events ordering them against the caller's stream;
+ * it owns no device memory: every buffer is passed per call, one set per `slot`
+ * (= iteration index mod SW_PIPELINE_SLOTS).  The caller's stream never waits on another
+ * stream: ring depth + host-side event checks replace device-side waits.
+ *
+ *   sw_ars_iteration_rollouts_f64   copy stream: deltas_host (pinned) -> deltas_dev
+ *                                   caller's stream: the 2*n_dir rollouts of this rank's shard
+ *                                   cov stream: sw_traj_moments_f64(traj) -> cov_acc (if given)
+ *   ... caller exchanges returns / moment rows between ranks (one all-gather) ...
+ *   sw_ars_iteration_update_f64     caller's stream: sw_ars_update_f64, then marks the slot free
+ *
+ * Before refilling deltas_host of a slot the host calls sw_ars_pipeline_host_slot_wait;
+ * before reading cov_acc it calls sw_ars_pipeline_sync_cov. */
+#define SW_PIPELINE_SLOTS 4
+typedef struct sw_ars_pipeline sw_ars_pipeline;
+
+int sw_ars_pipeline_create(sw_ars_pipeline **out);
+void sw_ars_pipeline_destroy(sw_ars_pipeline *pl);
+int sw_ars_pipeline_slots(void);
+int sw_ars_pipeline_host_slot_wait(sw_ars_pipeline *pl, int slot);
+int sw_ars_pipeline_sync_cov(sw_ars_pipeline *pl);
+/* enable != 0: record HIP events around every rollout launch on its stream (resets the log) */
+int sw_ars_pipeline_timing(sw_ars_pipeline *pl, int enable);
+int sw_ars_pipeline_rollout_ms(sw_ars_pipeline *pl, double *mean_ms, int64_t *launches);
+
+int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params *p,
+                                  int64_t n_dir_total, int64_t dir_begin, int64_t n_dir,
+                                  int32_t H, const double *deltas_host /* pinned host */,
+                                  double *deltas_dev, const double *policy, double nu,
+                                  const double *mean, const double *inv_std, double *returns,
+                                  double *traj, double *moments, double *cov_acc,
+                                  int32_t *status, void *stream);
+
+int sw_ars_iteration_update_f64(sw_ars_pipeline *pl, int slot, const sw_params *p,
+                                int64_t n_dir, const double *returns, const double *deltas_dev,
+                                double *policy, double alpha, double b, int64_t top_b,
+                                const double *moments, int64_t n_moment_rows, double *running,
+                                int64_t n_new_states, double *mean, double *inv_std,
+                                double *sigma_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,30 @@ _PROTOTYPES = {
                                          ctypes.c_void_p]),
     "sw_traj_moments_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sw_ars_pipeline_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "sw_ars_pipeline_destroy": (None, [ctypes.c_void_p]),
+    "sw_ars_pipeline_slots": (ctypes.c_int, []),
+    "sw_ars_pipeline_host_slot_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "sw_ars_pipeline_sync_cov": (ctypes.c_int, [ctypes.c_void_p]),
+    "sw_ars_pipeline_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "sw_ars_pipeline_rollout_ms": (ctypes.c_int, [ctypes.c_void_p,
+                                                  ctypes.POINTER(ctypes.c_double),
+                                                  ctypes.POINTER(ctypes.c_int64)]),
+    "sw_ars_iteration_rollouts_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int,
+                                                     ctypes.c_void_p, ctypes.c_int64,
+                                                     ctypes.c_int64, ctypes.c_int64,
+                                                     ctypes.c_int32, ctypes.c_void_p,
+                                                     ctypes.c_void_p, ctypes.c_void_p,
+                                                     ctypes.c_double] + [ctypes.c_void_p] * 8),
+    "sw_ars_iteration_update_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_void_p, ctypes.c_int64,
+                                                   ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_double,
+                                                   ctypes.c_double, ctypes.c_int64,
+                                                   ctypes.c_void_p, ctypes.c_int64,
+                                                   ctypes.c_void_p, ctypes.c_int64,
+                                                   ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 

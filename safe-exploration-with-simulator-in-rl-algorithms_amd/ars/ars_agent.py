@@ -80,23 +80,33 @@ class ARSAgent(object):
             if self.full_covariance else None
         self._sigma = torch.zeros(1, **f64)
         self.n_saved_states = 0
-        self.kernel_events = None  # set to [] to collect (start, end) events per rollout launch
 
         N, H = agent_param.N, agent_param.H
         self.lo, self.hi, self.chunk = shard_bounds(N, self.rank, self.world)
         self.n_local = self.hi - self.lo
         self.rows_chunk = kernels.moments_blocks(2 * self.chunk) if self.v2 else 0
-        self._deltas = torch.empty((N, self.m, self.d), **f64)
+        # Ring-buffered pipeline (slot = iteration mod ring depth), enqueued from native code
+        # (sw_ars_pipeline, include/swimmer_hip.h):
+        #   copy stream : H2D of the deltas, overlaps the tail of the previous iteration
+        #   main stream : rollouts -> all-gather -> update   (the critical path)
+        #   cov stream  : full-covariance pass over the recorded trajectories, off the
+        #                 critical path (only diag(cov) feeds the policy, and that comes from
+        #                 the moments fused into the rollout kernel)
+        self._pipe = kernels.ArsPipeline()
+        ring = self._pipe.slots
+        self._deltas2 = [torch.empty((N, self.m, self.d), **f64) for _ in range(ring)]
+        self._deltas = self._deltas2[0]
         self._deltas_host = [torch.empty((N, self.m, self.d), dtype=torch.float64).pin_memory()
-                             for _ in range(2)]
-        self._h2d_done = [None, None]
-        self._flip = 0
+                             for _ in range(ring)]
+        self._deltas_host_np = [t.numpy() for t in self._deltas_host]
+        self._it = 0
         self._returns_local = torch.empty(2 * self.n_local, **f64)
         self._moments_local = (torch.zeros((kernels.moments_blocks(2 * self.n_local),
                                             2 * self.d), **f64) if self.v2 else None)
         need_traj = self.full_covariance or record_trajectories
-        self._traj = (torch.empty((H, self.d, 2 * self.n_local), **f64)
-                      if need_traj and self.n_local > 0 else None)
+        self._traj2 = ([torch.empty((H, self.d, 2 * self.n_local), **f64) for _ in range(ring)]
+                       if need_traj and self.n_local > 0 else [None] * ring)
+        self._traj = self._traj2[0]
         self._status = torch.zeros(max(1, 2 * self.n_local), dtype=torch.int32,
                                    device=self.device)
 
@@ -128,7 +138,12 @@ class ARSAgent(object):
         var = self._inv_std.cpu().numpy() ** -2.0
         if not self.full_covariance:
             return np.diag(var)
-        acc = self._cov_acc.cpu().numpy()
+        self._pipe.sync_cov()
+        acc = self._cov_acc
+        if self.world > 1:   # sums are linear: reduce the per-rank partial sums only when read
+            acc = acc.clone()
+            dist.all_reduce(acc, group=self.group)
+        acc = acc.cpu().numpy()
         n, s1 = acc[0], acc[1:1 + self.d]
         s2 = acc[1 + self.d:].reshape(self.d, self.d)
         cov = (s2 - np.outer(s1, s1) / n) / (n - 1.0)
@@ -141,17 +156,6 @@ class ARSAgent(object):
         (N draws of rand(m, d) from the global generator consume the stream exactly like
         one rand(N, m, d))."""
         return 2 * np.random.rand(self.agent_param.N, self.m, self.d) - 1
-
-    def _upload_deltas(self, deltas):
-        i = self._flip
-        self._flip ^= 1
-        if self._h2d_done[i] is not None:
-            self._h2d_done[i].synchronize()
-        self._deltas_host[i].copy_(torch.from_numpy(np.ascontiguousarray(deltas)))
-        self._deltas.copy_(self._deltas_host[i], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._h2d_done[i] = ev
 
     def sort_directions(self, deltas, rewards):
         """Directions sorted by max(r+, r-), best first (ars_agent.py:97-108)."""
@@ -172,42 +176,33 @@ class ARSAgent(object):
         """One ARS iteration; returns the [2N] returns as a device tensor without
         synchronising the host."""
         ap = self.agent_param
-        if deltas is None:
-            deltas = self.sample_deltas()
-        self._upload_deltas(deltas)
-        if self.n_local > 0:
-            if self.kernel_events is not None:   # HIP events on the launch stream (bench.py)
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            kernels.ars_rollouts(self.params, ap.H, self._policy, self._deltas, ap.nu,
-                                 self.lo, self.n_local, mean=self._mean,
-                                 inv_std=self._inv_std, returns=self._returns_local,
-                                 traj=self._traj, moments=self._moments_local,
-                                 status=self._status)
-            if self.kernel_events is not None:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record()
-                self.kernel_events.append((e0, e1))
+        i = self._it % self._pipe.slots
+        self._it += 1
+        self._pipe.host_slot_wait(i)             # the slot's previous user is done with it
+        host = self._deltas_host_np[i]
+        if deltas is None:                       # same draws, same arithmetic as sample_deltas
+            host[...] = np.random.rand(ap.N, self.m, self.d)
+            host *= 2
+            host -= 1
+        else:
+            host[...] = deltas
+        self._deltas, self._traj = self._deltas2[i], self._traj2[i]
+        self._pipe.rollouts(i, self.params, ap.N, self.lo, self.n_local, ap.H,
+                            self._deltas_host[i], self._deltas, self._policy, ap.nu,
+                            self._mean, self._inv_std, self._returns_local, self._traj,
+                            self._moments_local,
+                            self._cov_acc if self._traj is not None else None, self._status)
         returns_all, moments_all = exchange(self._returns_local, self._moments_local, ap.N,
                                             self.world, self.group, self.rows_chunk)
         n_new = 2 * ap.N * ap.H
-        kernels.ars_update(self.params, returns_all, self._deltas, self._policy, ap.alpha,
-                           ap.b, self.top_b, moments=moments_all, running=self._running,
-                           n_new_states=n_new, mean=self._mean, inv_std=self._inv_std,
-                           sigma_out=self._sigma)
-        if self.full_covariance:
-            if self.world == 1:
-                kernels.traj_moments(self.params, self._traj, self._cov_acc)
-            else:
-                part = torch.zeros_like(self._cov_acc)
-                if self._traj is not None:
-                    kernels.traj_moments(self.params, self._traj, part)
-                dist.all_reduce(part, group=self.group)
-                self._cov_acc += part
+        self._pipe.update(i, self.params, ap.N, returns_all, self._deltas, self._policy,
+                          ap.alpha, ap.b, self.top_b, moments_all, self._running, n_new,
+                          self._mean, self._inv_std, self._sigma)
         if self.v2:
             self.n_saved_states += n_new
         if self.record_trajectories and self._traj is not None:
-            self.database.add_device_batch(self._traj.clone(), self._rollout_policies(deltas))
+            self.database.add_device_batch(self._traj.clone(),
+                                           self._rollout_policies(host.copy()))
         return returns_all
 
     def _rollout_policies(self, deltas):

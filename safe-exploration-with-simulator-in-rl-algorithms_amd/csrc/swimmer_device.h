@@ -110,14 +110,14 @@ __device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_o
     pc = fma3(pc, z, 4.16666666666666019037e-02);
     const double sr = __builtin_fma(r * z, ps, r);
     const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    // quadrant: q&1 swaps, q&2 negates sin, (q+1)&2 negates cos
-    const bool swap = (q & 1u) != 0u;
+    // quadrant: bit0 of q swaps sin/cos, bit1 negates sin, bit1 ^ bit0 (= (q+1)&2) negates cos
+    const uint32_t w = q << 30, t31 = q << 31;
+    const bool swap = t31 != 0u;
     const double sv = swap ? cr : sr;
     const double cv = swap ? sr : cr;
-    const uint64_t sflip = (uint64_t)(q & 2u) << 62;
-    const uint64_t cflip = (uint64_t)((q + 1u) & 2u) << 62;
-    s_out = __longlong_as_double(__double_as_longlong(sv) ^ (long long)sflip);
-    c_out = __longlong_as_double(__double_as_longlong(cv) ^ (long long)cflip);
+    const uint32_t sfl = w & 0x80000000u, cfl = (w ^ t31) & 0x80000000u;
+    s_out = __hiloint2double((int)((uint32_t)__double2hiint(sv) ^ sfl), __double2loint(sv));
+    c_out = __hiloint2double((int)((uint32_t)__double2hiint(cv) ^ cfl), __double2loint(cv));
 }
 
 // max(acc, |theta_i|): one v_max_f64 per angle; NaN angles are caught by the finiteness

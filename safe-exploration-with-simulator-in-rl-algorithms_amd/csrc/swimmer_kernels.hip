@@ -14,6 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <cstdlib>
+#include <new>
+#include <utility>
+#include <vector>
 
 #include "../../include/swimmer_hip.h"
 #include "swimmer_device.h"
@@ -309,7 +313,8 @@ rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict
 
 // ------------------------------------------------------------------------------------
 // n = 3, one segment per lane (swimmer_quad3.h): 16 rollouts per 64-thread workgroup.
-template <bool ARS>
+// TRAJ / MOM are compile-time so the hot loop carries no per-step uniform branches.
+template <bool ARS, bool TRAJ, bool MOM>
 __global__ void __launch_bounds__(kRollBlock)
 rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict__ policies,
                      const double *__restrict__ deltas, int64_t dir_begin, double nu,
@@ -359,11 +364,24 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         th = state0[(int64_t)cth * n_roll + r];
         thd = state0[(int64_t)cthd * n_roll + r];
     }
-    // byte offsets of this lane's three trajectory cells inside one step's [D][n_roll] slab
+    // Trajectory stores go through a buffer resource (SGPR base + per-step SGPR offset +
+    // per-lane VGPR offset): one store instruction per value and one scalar add per step,
+    // no per-store 64-bit address arithmetic.  The host picks this kernel only when the
+    // whole trajectory buffer is < 4 GiB (32-bit offsets; out-of-range stores are dropped
+    // by the hardware range check, never written elsewhere).
     const uint32_t off_th = (uint32_t)(((int64_t)cth * n_roll + r) * 8);
     const uint32_t off_thd = (uint32_t)(((int64_t)cthd * n_roll + r) * 8);
     const uint32_t off_g = (uint32_t)(((int64_t)(seg == 0 ? 0 : 1) * n_roll + r) * 8);
-    const int64_t slab = (int64_t)D * n_roll * 8;
+    const uint32_t slab = (uint32_t)(D * n_roll * 8);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        traj, 0, TRAJ ? (int)(uint32_t)((int64_t)H * slab) : 0, 0x00020000);
+    uint32_t soff = 0;
+    auto store_cell = [&](double v, uint32_t voff) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        union { double d; v2i i; } u;
+        u.d = v;
+        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, 0);
+    };
 
     double total = 0.0, thmax = 0.0, detmin = 1.0;
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
@@ -381,13 +399,13 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         asm("v_min_f64 %0, %1, %2" : "=v"(detmin) : "v"(detmin), "v"(det));
         total += __builtin_fma(gdx, C.dirx, gdy * C.diry);
         const double gsel = __builtin_fma(L.gx, gdx, L.gy * gdy);
-        if (traj) {
-            char *tb = (char *)traj + (int64_t)t * slab;
-            *(double *)(tb + off_th) = th;
-            *(double *)(tb + off_thd) = thd;
-            *(double *)(tb + off_g) = gsel;
+        if (TRAJ) {
+            store_cell(th, off_th);
+            store_cell(thd, off_thd);
+            store_cell(gsel, off_g);
+            soff += slab;
         }
-        if (moments) {
+        if (MOM) {
             const double a = th - kHalfPi;
             m1th += a;
             m2th = __builtin_fma(a, a, m2th);
@@ -413,7 +431,7 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         final_state[(int64_t)cthd * n_roll + r] = thd;
         if (q < 2) final_state[(int64_t)q * n_roll + r] = (q == 0) ? gdx : gdy;
     }
-    if (moments) {
+    if (MOM) {
         if (!valid) m1th = m2th = m1thd = m2thd = m1g = m2g = 0.0;
         // sum over the 16 rollouts of the wave, per segment lane: xor-butterfly over lane>>2
 #pragma unroll
@@ -533,7 +551,7 @@ ars_update_kernel(int d, int md, int64_t n_dir, const double *__restrict__ ret,
 // every load is a coalesced row segment; partial sums are reduced over the workgroup and
 // added to acc with fp64 atomics (d + d(d+1)/2 + 1 atomics per workgroup).
 constexpr int kMomBlock = 256;
-constexpr int kMomTChunk = 32;
+constexpr int kMomTChunk = 8;   // steps per workgroup: H/8 x R/256 workgroups keep >= 256 CUs fed
 
 template <int D>
 __global__ void __launch_bounds__(kMomBlock)
@@ -613,13 +631,35 @@ traj_moments_kernel(int64_t n_roll, int32_t H, const double *__restrict__ traj,
     default: return SW_ERR_SEGMENTS;           \
     }
 
+#define SW_DISPATCH_QUAD(ARS, HAS_TRAJ, HAS_MOM, STREAM, ...)                                   \
+    do {                                                                                         \
+        if (HAS_TRAJ) {                                                                          \
+            if (HAS_MOM)                                                                         \
+                hipLaunchKernelGGL((rollout_quad3_kernel<ARS, true, true>), dim3(grid),          \
+                                   dim3(kRollBlock), 0, STREAM, __VA_ARGS__);                    \
+            else                                                                                 \
+                hipLaunchKernelGGL((rollout_quad3_kernel<ARS, true, false>), dim3(grid),         \
+                                   dim3(kRollBlock), 0, STREAM, __VA_ARGS__);                    \
+        } else {                                                                                 \
+            if (HAS_MOM)                                                                         \
+                hipLaunchKernelGGL((rollout_quad3_kernel<ARS, false, true>), dim3(grid),         \
+                                   dim3(kRollBlock), 0, STREAM, __VA_ARGS__);                    \
+            else                                                                                 \
+                hipLaunchKernelGGL((rollout_quad3_kernel<ARS, false, false>), dim3(grid),        \
+                                   dim3(kRollBlock), 0, STREAM, __VA_ARGS__);                    \
+        }                                                                                        \
+    } while (0)
+
 // Kernel choice for rollouts: the quad (segment-per-lane) kernel while it still finds idle
 // SIMDs, the lane-per-rollout kernel beyond; sw_params.flags can force either.
-bool use_quad3(const sw_params *p, int64_t n_roll)
+bool use_quad3(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
 {
     if (p->n != 3) return false;
     if (p->flags & SW_FLAG_ROLLOUT_LANE) return false;
-    if (p->flags & SW_FLAG_ROLLOUT_QUAD) return n_roll < (int64_t)1 << 25;  // 32-bit cell offsets
+    // the quad kernel addresses the trajectory buffer with 32-bit byte offsets
+    if (with_traj && (int64_t)H * 8 * n_roll * 8 >= ((int64_t)1 << 32)) return false;
+    if (n_roll >= ((int64_t)1 << 25)) return false;
+    if (p->flags & SW_FLAG_ROLLOUT_QUAD) return true;
     return n_roll <= kQuadMaxRollouts;
 }
 
@@ -709,12 +749,12 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
     if (!policies || !returns) return SW_ERR_NULL;
     if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
-    if (use_quad3(p, n_roll)) {
+    if (use_quad3(p, n_roll, H, traj != nullptr)) {
         const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
-        hipLaunchKernelGGL((rollout_quad3_kernel<false>), dim3(grid), dim3(kRollBlock), 0,
-                           (hipStream_t)stream, C, n_roll, H, policies, (const double *)nullptr,
-                           (int64_t)0, 0.0, mean, inv_std, state0, returns, traj, final_state,
-                           moments, status);
+        SW_DISPATCH_QUAD(false, traj != nullptr, moments != nullptr,
+                         (hipStream_t)stream, C, n_roll, H, policies, (const double *)nullptr,
+                         (int64_t)0, 0.0, mean, inv_std, state0, returns, traj, final_state,
+                         moments, status);
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
@@ -738,12 +778,12 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
     if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
     const int64_t n_roll = 2 * n_dir;
-    if (use_quad3(p, n_roll)) {
+    if (use_quad3(p, n_roll, H, traj != nullptr)) {
         const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
-        hipLaunchKernelGGL((rollout_quad3_kernel<true>), dim3(grid), dim3(kRollBlock), 0,
-                           (hipStream_t)stream, C, n_roll, H, policy, deltas, dir_begin, nu, mean,
-                           inv_std, (const double *)nullptr, returns, traj, (double *)nullptr,
-                           moments, status);
+        SW_DISPATCH_QUAD(true, traj != nullptr, moments != nullptr,
+                         (hipStream_t)stream, C, n_roll, H, policy, deltas, dir_begin, nu, mean,
+                         inv_std, (const double *)nullptr, returns, traj, (double *)nullptr,
+                         moments, status);
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
@@ -785,6 +825,200 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
     SW_DISPATCH_N(p->n, hipLaunchKernelGGL(traj_moments_kernel<2 * NN + 2>, grid, dim3(kMomBlock), 0,
                                            (hipStream_t)stream, n_roll, H, traj, acc));
     return launch_status();
+}
+
+// ---- ARS iteration pipeline ---------------------------------------------------------
+// Host-side enqueue logic of one ARS iteration in native code: three streams and a ring of
+// SW_PIPELINE_SLOTS buffer slots per process, no device memory.
+//
+// Measured on MI355X (profiles/): a device-side cross-stream wait in front of the rollout
+// kernel (hipStreamWaitEvent on the H2D copy or on the covariance pass) delays that kernel
+// by 13-18 us every iteration even when the awaited work finished long ago.  So the critical
+// stream carries NO device-side waits: the ring is deep enough that everything a rollout
+// launch depends on (its deltas' H2D, the covariance pass that last read its trajectory
+// slot, the update that last read its delta slot) completed iterations ago, and the host
+// merely confirms that (hipEventSynchronize, normally already satisfied) before enqueueing.
+struct sw_ars_pipeline {
+    hipStream_t copy = nullptr, cov = nullptr;
+    hipEvent_t h2d_done[SW_PIPELINE_SLOTS] = {}, slot_free[SW_PIPELINE_SLOTS] = {},
+               cov_done[SW_PIPELINE_SLOTS] = {}, rolled = nullptr;
+    bool h2d_valid[SW_PIPELINE_SLOTS] = {}, free_valid[SW_PIPELINE_SLOTS] = {},
+         cov_valid[SW_PIPELINE_SLOTS] = {};
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // around each rollout launch
+    const double *cov_traj = nullptr;                      // covariance pass owed for this slot
+    double *cov_acc = nullptr;
+    int64_t cov_rolls = 0;
+    int32_t cov_H = 0;
+};
+
+int sw_ars_pipeline_create(sw_ars_pipeline **out)
+{
+    if (!out) return SW_ERR_NULL;
+    sw_ars_pipeline *pl = new (std::nothrow) sw_ars_pipeline();
+    if (!pl) return SW_ERR_LAUNCH;
+    const unsigned evf = hipEventDisableTiming;
+    bool ok = hipStreamCreateWithFlags(&pl->copy, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&pl->cov, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&pl->rolled, evf) == hipSuccess;
+    for (int i = 0; i < SW_PIPELINE_SLOTS && ok; ++i)
+        ok = hipEventCreateWithFlags(&pl->h2d_done[i], evf) == hipSuccess &&
+             hipEventCreateWithFlags(&pl->slot_free[i], evf) == hipSuccess &&
+             hipEventCreateWithFlags(&pl->cov_done[i], evf) == hipSuccess;
+    if (!ok) {
+        sw_ars_pipeline_destroy(pl);
+        return SW_ERR_LAUNCH;
+    }
+    *out = pl;
+    return SW_OK;
+}
+
+void sw_ars_pipeline_destroy(sw_ars_pipeline *pl)
+{
+    if (!pl) return;
+    if (pl->copy) (void)hipStreamSynchronize(pl->copy);
+    if (pl->cov) (void)hipStreamSynchronize(pl->cov);
+    for (auto &e : pl->timed) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    for (int i = 0; i < SW_PIPELINE_SLOTS; ++i) {
+        if (pl->h2d_done[i]) (void)hipEventDestroy(pl->h2d_done[i]);
+        if (pl->slot_free[i]) (void)hipEventDestroy(pl->slot_free[i]);
+        if (pl->cov_done[i]) (void)hipEventDestroy(pl->cov_done[i]);
+    }
+    if (pl->rolled) (void)hipEventDestroy(pl->rolled);
+    if (pl->copy) (void)hipStreamDestroy(pl->copy);
+    if (pl->cov) (void)hipStreamDestroy(pl->cov);
+    delete pl;
+}
+
+int sw_ars_pipeline_slots(void) { return SW_PIPELINE_SLOTS; }
+
+// The host may refill deltas_host[slot] once the update that last read the slot's device
+// copy is done (which implies its H2D left the pinned buffer long before).
+int sw_ars_pipeline_host_slot_wait(sw_ars_pipeline *pl, int slot)
+{
+    if (!pl) return SW_ERR_NULL;
+    if (slot < 0 || slot >= SW_PIPELINE_SLOTS) return SW_ERR_SIZE;
+    if (pl->h2d_valid[slot] && hipEventSynchronize(pl->h2d_done[slot]) != hipSuccess)
+        return SW_ERR_LAUNCH;
+    if (pl->free_valid[slot] && hipEventSynchronize(pl->slot_free[slot]) != hipSuccess)
+        return SW_ERR_LAUNCH;
+    return SW_OK;
+}
+
+int sw_ars_pipeline_sync_cov(sw_ars_pipeline *pl)
+{
+    if (!pl) return SW_ERR_NULL;
+    return hipStreamSynchronize(pl->cov) == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
+}
+
+int sw_ars_pipeline_timing(sw_ars_pipeline *pl, int enable)
+{
+    if (!pl) return SW_ERR_NULL;
+    pl->timing = enable != 0;
+    if (enable) {
+        for (auto &e : pl->timed) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        pl->timed.clear();
+    }
+    return SW_OK;
+}
+
+int sw_ars_pipeline_rollout_ms(sw_ars_pipeline *pl, double *mean_ms, int64_t *launches)
+{
+    if (!pl || !mean_ms || !launches) return SW_ERR_NULL;
+    double tot = 0.0;
+    for (auto &e : pl->timed) {
+        if (hipEventSynchronize(e.second) != hipSuccess) return SW_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.first, e.second) != hipSuccess) return SW_ERR_LAUNCH;
+        tot += ms;
+    }
+    *launches = (int64_t)pl->timed.size();
+    *mean_ms = pl->timed.empty() ? 0.0 : tot / (double)pl->timed.size();
+    return SW_OK;
+}
+
+int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params *p,
+                                  int64_t n_dir_total, int64_t dir_begin, int64_t n_dir, int32_t H,
+                                  const double *deltas_host, double *deltas_dev,
+                                  const double *policy, double nu, const double *mean,
+                                  const double *inv_std, double *returns, double *traj,
+                                  double *moments, double *cov_acc, int32_t *status, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!pl || !deltas_host || !deltas_dev) return SW_ERR_NULL;
+    if (slot < 0 || slot >= SW_PIPELINE_SLOTS || n_dir_total < dir_begin + n_dir) return SW_ERR_SIZE;
+    if (cov_acc && !traj && n_dir > 0) return SW_ERR_NULL;
+    hipStream_t main = (hipStream_t)stream;
+    const size_t bytes = (size_t)n_dir_total * (size_t)((p->n - 1) * (2 * p->n + 2)) * sizeof(double);
+    // host-confirmed: nothing still reads this slot's device deltas (update of it - SLOTS)
+    if (pl->free_valid[slot] && hipEventSynchronize(pl->slot_free[slot]) != hipSuccess)
+        return SW_ERR_LAUNCH;
+    if (hipMemcpyAsync(deltas_dev, deltas_host, bytes, hipMemcpyHostToDevice, pl->copy) != hipSuccess)
+        return SW_ERR_LAUNCH;
+    if (hipEventRecord(pl->h2d_done[slot], pl->copy) != hipSuccess) return SW_ERR_LAUNCH;
+    pl->h2d_valid[slot] = true;
+    // host-confirmed: the deltas have landed, and the covariance pass that last read this
+    // trajectory slot (it - SLOTS) is done -> the rollout launch needs no device-side wait
+    if (hipEventSynchronize(pl->h2d_done[slot]) != hipSuccess) return SW_ERR_LAUNCH;
+    if (pl->cov_valid[slot] && hipEventSynchronize(pl->cov_done[slot]) != hipSuccess)
+        return SW_ERR_LAUNCH;
+    if (n_dir > 0) {
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        if (pl->timing) {
+            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess ||
+                hipEventRecord(ev.first, main) != hipSuccess)
+                return SW_ERR_LAUNCH;
+        }
+        rc = sw_ars_rollouts_f64(p, dir_begin, n_dir, H, policy, deltas_dev, nu, mean, inv_std,
+                                 returns, traj, moments, status, stream);
+        if (pl->timing) {
+            (void)hipEventRecord(ev.second, main);
+            pl->timed.push_back(ev);
+        }
+        if (rc) return rc;
+    }
+    // The covariance pass over this iteration's trajectories is launched by
+    // sw_ars_iteration_update_f64, AFTER the update kernel: launched right behind the rollouts
+    // its ~500 workgroups queue in front of the update's 17 and triple the update's latency,
+    // which sits on the critical path; behind the update it overlaps the next rollouts.
+    pl->cov_traj = (cov_acc && n_dir > 0) ? traj : nullptr;
+    pl->cov_acc = cov_acc;
+    pl->cov_rolls = 2 * n_dir;
+    pl->cov_H = H;
+    return SW_OK;
+}
+
+int sw_ars_iteration_update_f64(sw_ars_pipeline *pl, int slot, const sw_params *p, int64_t n_dir,
+                                const double *returns, const double *deltas_dev, double *policy,
+                                double alpha, double b, int64_t top_b, const double *moments,
+                                int64_t n_moment_rows, double *running, int64_t n_new_states,
+                                double *mean, double *inv_std, double *sigma_out, void *stream)
+{
+    if (!pl) return SW_ERR_NULL;
+    if (slot < 0 || slot >= SW_PIPELINE_SLOTS) return SW_ERR_SIZE;
+    int rc = sw_ars_update_f64(p, n_dir, returns, deltas_dev, policy, alpha, b, top_b, moments,
+                               n_moment_rows, running, n_new_states, mean, inv_std, sigma_out,
+                               stream);
+    if (rc) return rc;
+    if (hipEventRecord(pl->slot_free[slot], (hipStream_t)stream) != hipSuccess) return SW_ERR_LAUNCH;
+    pl->free_valid[slot] = true;
+    if (pl->cov_traj) {
+        // slot_free also marks "rollouts of this slot done" for the cov stream
+        if (hipStreamWaitEvent(pl->cov, pl->slot_free[slot], 0) != hipSuccess) return SW_ERR_LAUNCH;
+        rc = sw_traj_moments_f64(p, pl->cov_rolls, pl->cov_H, pl->cov_traj, pl->cov_acc, pl->cov);
+        pl->cov_traj = nullptr;
+        if (rc) return rc;
+        if (hipEventRecord(pl->cov_done[slot], pl->cov) != hipSuccess) return SW_ERR_LAUNCH;
+        pl->cov_valid[slot] = true;
+    }
+    return SW_OK;
 }
 
 }  // extern "C"

@@ -151,3 +151,61 @@ def traj_moments(p: SwParams, traj, acc=None):
     check(load().sw_traj_moments_f64(ctypes.byref(p), n_roll, H, ptr(traj), ptr(acc),
                                      stream_ptr()), "sw_traj_moments_f64")
     return acc
+
+
+class ArsPipeline(object):
+    """Handle of a native sw_ars_pipeline (include/swimmer_hip.h): the double-buffered
+    copy / main / cov stream schedule of one ARS iteration, enqueued from C."""
+
+    def __init__(self):
+        require_gpu()
+        h = ctypes.c_void_p()
+        check(load().sw_ars_pipeline_create(ctypes.byref(h)), "sw_ars_pipeline_create")
+        self._h = h
+        self.slots = int(load().sw_ars_pipeline_slots())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            load().sw_ars_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def host_slot_wait(self, slot):
+        check(load().sw_ars_pipeline_host_slot_wait(self._h, slot), "sw_ars_pipeline_host_slot_wait")
+
+    def sync_cov(self):
+        check(load().sw_ars_pipeline_sync_cov(self._h), "sw_ars_pipeline_sync_cov")
+
+    def timing(self, enable):
+        check(load().sw_ars_pipeline_timing(self._h, 1 if enable else 0), "sw_ars_pipeline_timing")
+
+    def rollout_ms(self):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        check(load().sw_ars_pipeline_rollout_ms(self._h, ctypes.byref(ms), ctypes.byref(n)),
+              "sw_ars_pipeline_rollout_ms")
+        return ms.value, n.value
+
+    def rollouts(self, slot, p, n_dir_total, dir_begin, n_dir, H, deltas_host, deltas_dev, policy,
+                 nu, mean, inv_std, returns, traj, moments, cov_acc, status):
+        """deltas_host: pinned CPU tensor [n_dir_total, m, d]; everything else on the GPU."""
+        if not deltas_host.is_pinned() or not deltas_host.is_contiguous():
+            raise _lib.SwimmerHipError("deltas_host must be a contiguous pinned CPU tensor")
+        check(load().sw_ars_iteration_rollouts_f64(
+            self._h, slot, ctypes.byref(p), n_dir_total, dir_begin, n_dir, H,
+            ctypes.c_void_p(deltas_host.data_ptr()), ptr(deltas_dev), ptr(policy), float(nu),
+            ptr(mean), ptr(inv_std), ptr(returns), ptr(traj), ptr(moments), ptr(cov_acc),
+            ptr(status), stream_ptr()), "sw_ars_iteration_rollouts_f64")
+
+    def update(self, slot, p, n_dir, returns, deltas_dev, policy, alpha, b, top_b, moments,
+               running, n_new_states, mean, inv_std, sigma_out):
+        n_rows = 0 if moments is None else moments.shape[0]
+        check(load().sw_ars_iteration_update_f64(
+            self._h, slot, ctypes.byref(p), n_dir, ptr(returns), ptr(deltas_dev), ptr(policy),
+            float(alpha), float(b), int(top_b), ptr(moments), n_rows, ptr(running),
+            int(n_new_states), ptr(mean), ptr(inv_std), ptr(sigma_out), stream_ptr()),
+            "sw_ars_iteration_update_f64")
