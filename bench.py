@@ -100,13 +100,14 @@ def aux_step_only(sw, n, device):
         ac = torch.as_tensor(rng.uniform(-1, 1, (m, B)), device=device)
         nxt = torch.empty_like(st)
         rew = torch.empty(B, dtype=torch.float64, device=device)
+        plan = sw.kernels.StepPlan(p, st, ac, nxt, rew)   # pre-bound launch, one foreign call
         for _ in range(5):
-            sw.kernels.step(p, st, ac, out=nxt, reward=rew)
+            plan.launch()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            sw.kernels.step(p, st, ac, out=nxt, reward=rew)
+            plan.launch()
         e1.record()
         torch.cuda.synchronize()
         per = e0.elapsed_time(e1) * 1e-3 / reps

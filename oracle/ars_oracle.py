@@ -13,7 +13,8 @@ from . import swimmer_oracle as so
 class ArsOracle(object):
     """State of one reference ARSAgent: policy, V2 mean / covariance, every saved state."""
 
-    def __init__(self, n, l_i, m_i, k, h, H, N, b, alpha, nu, V1, seed, policy0=None):
+    def __init__(self, n, l_i, m_i, k, h, H, N, b, alpha, nu, V1, seed, policy0=None, top_b=0):
+        self.top_b = top_b   # > 0: safe_ars/ars.py:95-96 semantics (only the best top_b directions)
         self.p = so.OracleParams.make(n, l_i, m_i, k, h)   # direction stays (1, 0)
         self.m, self.d = n - 1, 2 * n + 2
         self.H, self.N, self.b, self.alpha, self.nu, self.V1 = H, N, b, alpha, nu, V1
@@ -35,6 +36,8 @@ class ArsOracle(object):
                     self.saved.append(traj)
         r = np.array(rewards).reshape(self.N, 2)
         order = np.argsort(r.max(axis=1))[::-1]                    # :105-108
+        if self.top_b > 0:
+            order = order[:self.top_b]                              # safe_ars/ars.py:96
         used = r[order].reshape(-1)
         sigma = np.std(used)                                       # :123 (ddof = 0)
         grad = np.zeros_like(self.policy)

@@ -141,7 +141,7 @@ class ARSAgent(object):
         self._pipe.sync_cov()
         acc = self._cov_acc
         if self.world > 1:   # sums are linear: reduce the per-rank partial sums only when read
-            acc = acc.clone()
+            acc = acc.cpu() if dist.get_backend(self.group) == "gloo" else acc.clone()
             dist.all_reduce(acc, group=self.group)
         acc = acc.cpu().numpy()
         n, s1 = acc[0], acc[1:1 + self.d]
@@ -214,6 +214,56 @@ class ARSAgent(object):
         out[0::2] = P + nd
         out[1::2] = P - nd
         return out
+
+    # ---- checkpoint / resume (the reference only saves the policy, ars_agent.py:218-219) ----
+    def save_checkpoint(self, path):
+        """Everything needed to continue training bit for bit: policy, V2 running sums,
+        covariance sums, iteration count and NumPy's global generator state.  Plain arrays
+        in an .npz (no pickle).  Collective when distributed; rank 0 writes."""
+        torch.cuda.synchronize(self.device)
+        self._pipe.sync_cov()
+        kind, key, pos, has_gauss, cached = np.random.get_state()
+        assert kind == "MT19937"
+        cov = None
+        if self.full_covariance:
+            cov = self._cov_acc
+            if self.world > 1:
+                cov = cov.cpu() if dist.get_backend(self.group) == "gloo" else cov.clone()
+                dist.all_reduce(cov, group=self.group)
+            cov = cov.cpu().numpy()
+        if self.rank == 0:
+            data = dict(policy=self.policy, n_saved_states=np.int64(self.n_saved_states),
+                        iteration=np.int64(self._it), rng_key=key, rng_pos=np.int64(pos),
+                        rng_has_gauss=np.int64(has_gauss), rng_cached=np.float64(cached),
+                        v2=np.int64(self.v2))
+            if self.v2:
+                data.update(mean=self._mean.cpu().numpy(), inv_std=self._inv_std.cpu().numpy(),
+                            running=self._running.cpu().numpy())
+            if cov is not None:
+                data["cov_acc"] = cov
+            with open(path, "wb") as f:
+                np.savez(f, **data)
+
+    def load_checkpoint(self, path):
+        z = np.load(path, allow_pickle=False)
+        if bool(z["v2"]) != self.v2 or z["policy"].shape != (self.m, self.d):
+            raise SwimmerHipError("checkpoint does not match this agent's configuration")
+        dev = self.device
+        self._policy.copy_(torch.as_tensor(z["policy"], device=dev))
+        if self.v2:
+            self._mean.copy_(torch.as_tensor(z["mean"], device=dev))
+            self._inv_std.copy_(torch.as_tensor(z["inv_std"], device=dev))
+            self._running.copy_(torch.as_tensor(z["running"], device=dev))
+        if self.full_covariance:
+            self._pipe.sync_cov()
+            if "cov_acc" in z.files and self.rank == 0:   # per-rank sums add up to the total
+                self._cov_acc.copy_(torch.as_tensor(z["cov_acc"], device=dev))
+            else:
+                self._cov_acc.zero_()
+        self.n_saved_states = int(z["n_saved_states"])
+        self._it = int(z["iteration"])
+        np.random.set_state(("MT19937", z["rng_key"], int(z["rng_pos"]), int(z["rng_has_gauss"]),
+                             float(z["rng_cached"])))
 
     def runOneIteration(self):
         """One whole ARS iteration (ars_agent.py:132-185); returns the list of 2N returns."""

@@ -44,6 +44,9 @@ def exchange(returns_local, moments_local, n_dir, world, group=None, rows_chunk=
         return returns_local, moments_local
     w = 0 if moments_local is None else moments_local.shape[1]
     buf = pack_local(returns_local, moments_local, chunk, rows_chunk)
+    device = buf.device
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        buf = buf.cpu()   # gloo has no GPU all-gather: stage through the host (tests / debugging)
     out = torch.empty((world, buf.numel()), dtype=torch.float64, device=buf.device)
     try:
         dist.all_gather_into_tensor(out, buf, group=group)
@@ -51,6 +54,7 @@ def exchange(returns_local, moments_local, n_dir, world, group=None, rows_chunk=
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf, group=group)
         out = torch.stack(parts)
+    out = out.to(device)
     returns_all = out[:, :2 * chunk].reshape(-1)[:2 * n_dir].contiguous()
     moments_all = None
     if moments_local is not None:

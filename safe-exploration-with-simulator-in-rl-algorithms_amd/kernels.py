@@ -44,6 +44,30 @@ def step(p: SwParams, state, action, out=None, reward=None, status=None):
     return out, reward
 
 
+class StepPlan(object):
+    """A pre-bound sw_step_f64 launch: all argument conversion is done once, `launch()` is a
+    single foreign call (the per-launch Python overhead of `step()` is larger than the 8192-env
+    kernel itself).  Launches on the stream that was current when the plan was made."""
+
+    def __init__(self, p: SwParams, state, action, out, reward=None, status=None):
+        require_gpu()
+        n_env = state.shape[1]
+        _want(state, "state", (p.d, n_env))
+        _want(action, "action", (p.m, n_env))
+        _want(out, "out", (p.d, n_env))
+        if reward is not None:
+            _want(reward, "reward", (n_env,))
+        self._keep = (p, state, action, out, reward, status)
+        self._fn = load().sw_step_f64
+        self._args = (ctypes.byref(p), n_env, ptr(state), ptr(action), ptr(out), ptr(reward),
+                      ptr(status), stream_ptr())
+
+    def launch(self):
+        rc = self._fn(*self._args)
+        if rc:
+            check(rc, "sw_step_f64")
+
+
 def accelerations(p: SwParams, state, action):
     """SwimmerEnv.compute_accelerations -> (Gdd [2, n_env], thdd [n, n_env])."""
     require_gpu()

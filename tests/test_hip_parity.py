@@ -271,3 +271,61 @@ def test_ars_training_and_store(sw, golden, tmp_path):
     agent.database.save(str(tmp_path / "db.npz"))
     z = np.load(tmp_path / "db.npz")
     assert z["policies"].shape == (5 * 6, 2, 8) and z["trajectories"].shape == (5 * 6, 60, 8)
+
+
+def test_top_b_variant_matches_safe_ars_semantics(sw):
+    """safe_ars/ars.py:48-65, :95-96: only the best b directions enter sigma_R and the step."""
+    from oracle.ars_oracle import ArsOracle
+    N, b, H = 8, 3, 80
+    ep = sw.EnvParam("LeonSwimmer-Test", n=3, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("Test", V1=True, n_iter=3, H=H, N=N, b=b, alpha=0.01, nu=0.02, safe=False,
+                     threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=4, top_b=b)
+    o = ArsOracle(3, 1.0, 1.0, 10.0, 1e-3, H, N, b, 0.01, 0.02, True, 4, top_b=b)
+    for it in range(3):
+        r = np.array(agent.runOneIteration())
+        ro = np.array(o.iteration())
+        assert np.abs(r - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
+        assert np.abs(agent.policy - o.policy).max() <= 1e-9
+
+
+def test_checkpoint_resume_is_bit_exact(sw, tmp_path):
+    ep = sw.EnvParam("LeonSwimmer-Test", n=3, H=150, l_i=0.8, m_i=1.2, h=1e-3, k=10.2, epsilon=0)
+    ap = sw.ARSParam("Test", V1=False, n_iter=4, H=150, N=6, b=6, alpha=0.0075, nu=0.01,
+                     safe=False, threshold=0, initial_w="Zero")
+    a = sw.ARSAgent(ep, ap, seed=9)
+    for _ in range(2):
+        a.runOneIteration()
+    a.save_checkpoint(str(tmp_path / "ck.npz"))
+    tail_a = [a.runOneIteration() for _ in range(2)]
+    b = sw.ARSAgent(ep, ap, seed=12345)          # different seed: the checkpoint restores the stream
+    b.load_checkpoint(str(tmp_path / "ck.npz"))
+    tail_b = [b.runOneIteration() for _ in range(2)]
+    assert np.array_equal(np.array(tail_a), np.array(tail_b))
+    assert np.array_equal(a.policy, b.policy) and np.array_equal(a.mean, b.mean)
+    assert a.n_saved_states == b.n_saved_states
+    sd = np.sqrt(np.diag(a.covariance))
+    assert (np.abs(a.covariance - b.covariance) <= 1e-12 * np.outer(sd, sd)).all()
+
+
+def test_vec_env_matches_oracle_over_steps(sw):
+    """VecSwimmerEnv (pre-bound launches, double-buffered SoA state) vs the oracle."""
+    rng = np.random.default_rng(3)
+    B, n, T = 300, 3, 25
+    env = sw.VecSwimmerEnv(B, n=n, l_i=0.8, m_i=1.2, k=10.2, h=1e-3)
+    st = np.empty((B, 8))
+    st[:, 0:2] = rng.uniform(-0.5, 0.5, (B, 2))
+    st[:, 2::2] = rng.uniform(-np.pi, np.pi, (B, n))
+    st[:, 3::2] = rng.uniform(-2, 2, (B, n))
+    env.set_state(np.ascontiguousarray(st.T))
+    act_dev = torch.empty((2, B), dtype=torch.float64, device="cuda:0")
+    op = oracle.OracleParams.make(n, 0.8, 1.2, 10.2, 1e-3)
+    for t in range(T):
+        ac = rng.uniform(-5, 5, (B, 2))
+        act_dev.copy_(torch.as_tensor(np.ascontiguousarray(ac.T)))
+        s_dev, r_dev, done, info = env.step(act_dev)
+        st, rew = oracle.step_batch(op, st, ac)
+        assert done is False and info == {}
+        assert np.abs(s_dev.T.cpu().numpy() - st).max() <= 1e-11
+        assert np.abs(r_dev.cpu().numpy() - rew).max() <= 1e-11
+    assert len(env._plans) == 2     # two pre-bound launches (A->B, B->A), reused
