@@ -150,12 +150,12 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        agent.run_iteration_async()
+        agent.run_iteration_async(want_returns=False)
     sync()
     agent._pipe.timing(True)   # HIP events around every rollout launch, on its stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        agent.run_iteration_async()
+        agent.run_iteration_async(want_returns=False)
     sync()
     dt = time.perf_counter() - t0
     kern_ms, kern_launches = agent._pipe.rollout_ms()

@@ -149,6 +149,17 @@ int sw_ars_update_f64(const sw_params *p, int64_t n_dir, const double *returns,
                       double *running, int64_t n_new_states, double *mean, double *inv_std,
                       double *sigma_out, void *stream);
 
+/* The same update reading an all-gathered buffer in place (no repacking between the
+ * collective and the update):  gathered = `world` segments of
+ * seg_len = 2*chunk + rows_chunk*2d doubles, segment r =
+ * [2*chunk returns of directions r*chunk .. | rows_chunk moment rows]  (zero padded).
+ * world = 1 is a single rank's own segment. */
+int sw_ars_update_gathered_f64(const sw_params *p, int64_t n_dir, const double *gathered,
+                               int32_t world, int64_t chunk, int64_t rows_chunk,
+                               const double *deltas, double *policy, double alpha, double b,
+                               int64_t top_b, double *running, int64_t n_new_states,
+                               double *mean, double *inv_std, double *sigma_out, void *stream);
+
 /* Full first and second moments of recorded trajectories (for the `covariance` attribute):
  * acc[0] += count, acc[1..d] += sum(s - c), acc[1+d + f*d + g] += sum((s-c)_f (s-c)_g),
  * over traj [H][d][n_roll]; acc is [1 + d + d*d] and must be zeroed by the caller before
@@ -168,8 +179,9 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
  *   sw_ars_iteration_rollouts_f64   copy stream: deltas_host (pinned) -> deltas_dev
  *                                   caller's stream: the 2*n_dir rollouts of this rank's shard
  *                                   cov stream: sw_traj_moments_f64(traj) -> cov_acc (if given)
- *   ... caller exchanges returns / moment rows between ranks (one all-gather) ...
- *   sw_ars_iteration_update_f64     caller's stream: sw_ars_update_f64, then marks the slot free
+ *   ... caller all-gathers its segment [returns | moment rows] between ranks ...
+ *   sw_ars_iteration_update_f64     caller's stream: sw_ars_update_gathered_f64 on the gathered
+ *                                   buffer, then marks the slot free and launches the cov pass
  *
  * Before refilling deltas_host of a slot the host calls sw_ars_pipeline_host_slot_wait;
  * before reading cov_acc it calls sw_ars_pipeline_sync_cov. */
@@ -194,11 +206,11 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
                                   int32_t *status, void *stream);
 
 int sw_ars_iteration_update_f64(sw_ars_pipeline *pl, int slot, const sw_params *p,
-                                int64_t n_dir, const double *returns, const double *deltas_dev,
+                                int64_t n_dir, const double *gathered, int32_t world,
+                                int64_t chunk, int64_t rows_chunk, const double *deltas_dev,
                                 double *policy, double alpha, double b, int64_t top_b,
-                                const double *moments, int64_t n_moment_rows, double *running,
-                                int64_t n_new_states, double *mean, double *inv_std,
-                                double *sigma_out, void *stream);
+                                double *running, int64_t n_new_states, double *mean,
+                                double *inv_std, double *sigma_out, void *stream);
 
 #ifdef __cplusplus
 }

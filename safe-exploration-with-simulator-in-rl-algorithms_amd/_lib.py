@@ -98,13 +98,23 @@ _PROTOTYPES = {
                                                      ctypes.c_double] + [ctypes.c_void_p] * 8),
     "sw_ars_iteration_update_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int,
                                                    ctypes.c_void_p, ctypes.c_int64,
+                                                   ctypes.c_void_p, ctypes.c_int32,
+                                                   ctypes.c_int64, ctypes.c_int64,
                                                    ctypes.c_void_p, ctypes.c_void_p,
-                                                   ctypes.c_void_p, ctypes.c_double,
-                                                   ctypes.c_double, ctypes.c_int64,
-                                                   ctypes.c_void_p, ctypes.c_int64,
-                                                   ctypes.c_void_p, ctypes.c_int64,
+                                                   ctypes.c_double, ctypes.c_double,
+                                                   ctypes.c_int64, ctypes.c_void_p,
+                                                   ctypes.c_int64, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_void_p,
-                                                   ctypes.c_void_p, ctypes.c_void_p]),
+                                                   ctypes.c_void_p]),
+    "sw_ars_update_gathered_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64,
+                                                  ctypes.c_void_p, ctypes.c_int32,
+                                                  ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_double, ctypes.c_double,
+                                                  ctypes.c_int64, ctypes.c_void_p,
+                                                  ctypes.c_int64, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 

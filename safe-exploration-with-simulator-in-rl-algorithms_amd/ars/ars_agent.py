@@ -27,7 +27,8 @@ from .. import kernels
 from .._lib import SwParams, SwimmerHipError, kernel_flags, require_gpu
 from .database import Database
 from .environment import Environment
-from .sharding import exchange, shard_bounds
+from .sharding import (all_gather_segments, returns_from_segments, segment_len,
+                       shard_bounds)
 
 
 class ARSAgent(object):
@@ -100,9 +101,18 @@ class ARSAgent(object):
                              for _ in range(ring)]
         self._deltas_host_np = [t.numpy() for t in self._deltas_host]
         self._it = 0
-        self._returns_local = torch.empty(2 * self.n_local, **f64)
-        self._moments_local = (torch.zeros((kernels.moments_blocks(2 * self.n_local),
-                                            2 * self.d), **f64) if self.v2 else None)
+        # This rank's results live in ONE packed segment [2*chunk returns | moment rows]
+        # (zero padded): the kernels write into views of it, the all-gather ships it as is,
+        # and the update kernel indexes the gathered buffer in place.
+        width = 2 * self.d
+        self._seg_len = segment_len(self.chunk, self.rows_chunk, width)
+        self._send = torch.zeros(self._seg_len, **f64)
+        self._gathered = (torch.zeros(self.world * self._seg_len, **f64)
+                          if self.world > 1 else self._send)
+        self._returns_local = self._send[:2 * self.n_local]
+        rows_local = kernels.moments_blocks(2 * self.n_local) if self.v2 else 0
+        self._moments_local = (self._send[2 * self.chunk:2 * self.chunk + rows_local * width]
+                               .view(rows_local, width) if self.v2 else None)
         need_traj = self.full_covariance or record_trajectories
         self._traj2 = ([torch.empty((H, self.d, 2 * self.n_local), **f64) for _ in range(ring)]
                        if need_traj and self.n_local > 0 else [None] * ring)
@@ -172,9 +182,10 @@ class ARSAgent(object):
         kernels.ars_update(self.params, r, d, self._policy, self.agent_param.alpha,
                            self.agent_param.b, 0, sigma_out=self._sigma)
 
-    def run_iteration_async(self, deltas=None):
-        """One ARS iteration; returns the [2N] returns as a device tensor without
-        synchronising the host."""
+    def run_iteration_async(self, deltas=None, want_returns=True):
+        """One ARS iteration without synchronising the host; returns the [2N] returns as a
+        device tensor (a view of the result segment, valid until the next iteration), or
+        None with want_returns=False."""
         ap = self.agent_param
         i = self._it % self._pipe.slots
         self._it += 1
@@ -192,18 +203,20 @@ class ARSAgent(object):
                             self._mean, self._inv_std, self._returns_local, self._traj,
                             self._moments_local,
                             self._cov_acc if self._traj is not None else None, self._status)
-        returns_all, moments_all = exchange(self._returns_local, self._moments_local, ap.N,
-                                            self.world, self.group, self.rows_chunk)
+        gathered = all_gather_segments(self._send, self._gathered, self.world, self.group)
         n_new = 2 * ap.N * ap.H
-        self._pipe.update(i, self.params, ap.N, returns_all, self._deltas, self._policy,
-                          ap.alpha, ap.b, self.top_b, moments_all, self._running, n_new,
-                          self._mean, self._inv_std, self._sigma)
+        self._pipe.update(i, self.params, ap.N, gathered, self.world, self.chunk,
+                          self.rows_chunk, self._deltas, self._policy, ap.alpha, ap.b,
+                          self.top_b, self._running, n_new, self._mean, self._inv_std,
+                          self._sigma)
         if self.v2:
             self.n_saved_states += n_new
         if self.record_trajectories and self._traj is not None:
             self.database.add_device_batch(self._traj.clone(),
                                            self._rollout_policies(host.copy()))
-        return returns_all
+        if not want_returns:
+            return None
+        return returns_from_segments(gathered, ap.N, self.world, self.chunk)
 
     def _rollout_policies(self, deltas):
         """Host copy of the 2*n_local perturbed policies of this rank's shard, in rollout

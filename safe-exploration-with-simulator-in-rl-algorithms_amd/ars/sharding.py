@@ -60,3 +60,32 @@ def exchange(returns_local, moments_local, n_dir, world, group=None, rows_chunk=
     if moments_local is not None:
         moments_all = out[:, 2 * chunk:].reshape(world * rows_chunk, w).contiguous()
     return returns_all, moments_all
+
+
+def segment_len(chunk, rows_chunk, width):
+    """Doubles in one rank's packed segment [2*chunk returns | rows_chunk x width moments]."""
+    return 2 * chunk + rows_chunk * width
+
+
+def all_gather_segments(send, gathered, world, group=None):
+    """gathered[r*L:(r+1)*L] <- rank r's `send` (L doubles).  One collective, no repacking:
+    the rollout kernel writes returns and moment rows straight into `send`, and the update
+    kernel indexes `gathered` in place (sw_ars_update_gathered_f64)."""
+    if world == 1:
+        return send
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no GPU all-gather: stage through the host (tests / debugging only)
+        parts = [torch.empty(send.numel(), dtype=send.dtype) for _ in range(world)]
+        dist.all_gather(parts, send.cpu(), group=group)
+        gathered.copy_(torch.cat(parts))
+        return gathered
+    dist.all_gather_into_tensor(gathered, send, group=group)
+    return gathered
+
+
+def returns_from_segments(gathered, n_dir, world, chunk):
+    """The [2*n_dir] returns in direction order out of the gathered segments."""
+    if world == 1:
+        return gathered[:2 * n_dir]
+    seg = gathered.numel() // world
+    return gathered.view(world, seg)[:, :2 * chunk].reshape(-1)[:2 * n_dir].contiguous()

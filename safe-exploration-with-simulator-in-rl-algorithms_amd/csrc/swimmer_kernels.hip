@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <climits>
 #include <cstdlib>
 #include <new>
 #include <utility>
@@ -471,15 +472,34 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return t;
 }
 
+// Where the update finds an iteration's results.  After the all-gather every rank's segment
+// [2*chunk returns | rows_chunk moment rows] sits at rank*seg_len in one buffer; the kernel
+// indexes that layout directly so no repacking kernels run between the collective and the
+// update.  Separate returns / moments arrays are the world = 1 special case.
+struct GatherView {
+    const double *ret_base;
+    const double *mom_base;
+    int64_t seg_len;      // doubles between consecutive ranks' segments
+    int32_t chunk;        // direction slots per rank
+    int32_t rows_chunk;   // moment rows per rank
+    int32_t world;
+};
+
+__device__ __forceinline__ double ret_at(const GatherView &g, int32_t dir, int sign_idx)
+{
+    const int32_t rank = dir / g.chunk, local = dir - rank * g.chunk;
+    return g.ret_base[rank * g.seg_len + 2 * local + sign_idx];
+}
+
 // used(i): all directions (top_b == 0) or the top_b by max(r+, r-), ties to the higher index
 // (argsort ascending, reversed: ars_agent.py:105-108).
-__device__ __forceinline__ bool dir_used(const double *ret, int64_t n_dir, int64_t top_b, int64_t i)
+__device__ __forceinline__ bool dir_used(const GatherView &g, int32_t n_dir, int64_t top_b, int32_t i)
 {
     if (top_b <= 0 || top_b >= n_dir) return true;
-    const double ki = fmax(ret[2 * i], ret[2 * i + 1]);
+    const double ki = fmax(ret_at(g, i, 0), ret_at(g, i, 1));
     int64_t rank = 0;
-    for (int64_t j = 0; j < n_dir; ++j) {
-        const double kj = fmax(ret[2 * j], ret[2 * j + 1]);
+    for (int32_t j = 0; j < n_dir; ++j) {
+        const double kj = fmax(ret_at(g, j, 0), ret_at(g, j, 1));
         rank += (kj > ki) || (kj == ki && j > i);
     }
     return rank < top_b;
@@ -488,10 +508,9 @@ __device__ __forceinline__ bool dir_used(const double *ret, int64_t n_dir, int64
 // grid = m*d + 1 workgroups.  Workgroup e < m*d updates policy entry e; the last one merges
 // the V2 statistics.  Every workgroup recomputes sigma_R (2 n_dir values, L2-resident).
 __global__ void __launch_bounds__(kUpdBlock)
-ars_update_kernel(int d, int md, int64_t n_dir, const double *__restrict__ ret,
+ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                   const double *__restrict__ deltas, double *__restrict__ policy, double alpha,
-                  double b, int64_t top_b, const double *__restrict__ moments,
-                  int64_t n_rows, double *__restrict__ running, double n_new,
+                  double b, int64_t top_b, double *__restrict__ running, double n_new,
                   double *__restrict__ mean, double *__restrict__ inv_std,
                   double *__restrict__ sigma_out)
 {
@@ -500,20 +519,21 @@ ars_update_kernel(int d, int md, int64_t n_dir, const double *__restrict__ ret,
     if (e < md) {
         // np.std(used_rewards): two-pass, ddof = 0 (ars_agent.py:123)
         double s = 0.0, cnt = 0.0;
-        for (int64_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
-            if (dir_used(ret, n_dir, top_b, i)) {
-                s += ret[2 * i] + ret[2 * i + 1];
+        for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+            if (dir_used(gv, n_dir, top_b, i)) {
+                s += ret_at(gv, i, 0) + ret_at(gv, i, 1);
                 cnt += 2.0;
             }
         s = block_sum(s, sh);
         cnt = block_sum(cnt, sh);
         const double mu = s / cnt;
         double v = 0.0, g = 0.0;
-        for (int64_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
-            if (dir_used(ret, n_dir, top_b, i)) {
-                const double a = ret[2 * i] - mu, c = ret[2 * i + 1] - mu;
+        for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+            if (dir_used(gv, n_dir, top_b, i)) {
+                const double rp = ret_at(gv, i, 0), rm = ret_at(gv, i, 1);
+                const double a = rp - mu, c = rm - mu;
                 v += a * a + c * c;
-                g = __builtin_fma(ret[2 * i] - ret[2 * i + 1], deltas[i * md + e], g);
+                g = __builtin_fma(rp - rm, deltas[(int64_t)i * md + e], g);
             }
         v = block_sum(v, sh);
         g = block_sum(g, sh);
@@ -524,12 +544,15 @@ ars_update_kernel(int d, int md, int64_t n_dir, const double *__restrict__ ret,
             if (e == 0 && sigma_out) *sigma_out = sigma;
         }
     } else if (running != nullptr) {
-        // V2: merge this iteration's per-workgroup partial sums (fixed order) into the
-        // running sums, then mean = c + S1/n, var = (S2 - S1^2/n)/(n-1) (np.cov, ddof = 1)
+        // V2: merge this iteration's partial sums (rank-major, row by row: a fixed order that
+        // is the same on every rank) into the running sums, then mean = c + S1/n,
+        // var = (S2 - S1^2/n)/(n-1) (np.cov, ddof = 1)
         const int j = threadIdx.x;
         if (j < 2 * d) {
             double a = 0.0;
-            for (int64_t row = 0; row < n_rows; ++row) a += moments[row * (2 * d) + j];
+            for (int32_t r = 0; r < gv.world; ++r)
+                for (int32_t row = 0; row < gv.rows_chunk; ++row)
+                    a += gv.mom_base[r * gv.seg_len + (int64_t)row * (2 * d) + j];
             running[1 + j] += a;
         }
         __syncthreads();
@@ -794,6 +817,18 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
     return launch_status();
 }
 
+static int launch_update(const sw_params *p, int64_t n_dir, const GatherView &gv,
+                         const double *deltas, double *policy, double alpha, double b,
+                         int64_t top_b, double *running, int64_t n_new_states, double *mean,
+                         double *inv_std, double *sigma_out, void *stream)
+{
+    const int d = 2 * p->n + 2, md = (p->n - 1) * d;
+    hipLaunchKernelGGL(ars_update_kernel, dim3(md + 1), dim3(kUpdBlock), 0, (hipStream_t)stream, d,
+                       md, (int32_t)n_dir, gv, deltas, policy, alpha, b, top_b, running,
+                       (double)n_new_states, mean, inv_std, sigma_out);
+    return launch_status();
+}
+
 int sw_ars_update_f64(const sw_params *p, int64_t n_dir, const double *returns,
                       const double *deltas, double *policy, double alpha, double b, int64_t top_b,
                       const double *moments, int64_t n_moment_rows, double *running,
@@ -802,14 +837,36 @@ int sw_ars_update_f64(const sw_params *p, int64_t n_dir, const double *returns,
 {
     int rc = check_params(p);
     if (rc) return rc;
-    if (n_dir <= 0 || n_moment_rows < 0 || n_new_states < 0) return SW_ERR_SIZE;
+    if (n_dir <= 0 || n_dir > INT32_MAX / 4 || n_moment_rows < 0 || n_moment_rows > INT32_MAX ||
+        n_new_states < 0)
+        return SW_ERR_SIZE;
     if (!returns || !deltas || !policy) return SW_ERR_NULL;
     if (running && (!moments || !mean || !inv_std)) return SW_ERR_NULL;
-    const int d = 2 * p->n + 2, md = (p->n - 1) * d;
-    hipLaunchKernelGGL(ars_update_kernel, dim3(md + 1), dim3(kUpdBlock), 0, (hipStream_t)stream, d,
-                       md, n_dir, returns, deltas, policy, alpha, b, top_b, moments, n_moment_rows,
-                       running, (double)n_new_states, mean, inv_std, sigma_out);
-    return launch_status();
+    const GatherView gv{returns, moments, 0, (int32_t)n_dir, (int32_t)n_moment_rows, 1};
+    return launch_update(p, n_dir, gv, deltas, policy, alpha, b, top_b, running, n_new_states,
+                         mean, inv_std, sigma_out, stream);
+}
+
+int sw_ars_update_gathered_f64(const sw_params *p, int64_t n_dir, const double *gathered,
+                               int32_t world, int64_t chunk, int64_t rows_chunk,
+                               const double *deltas, double *policy, double alpha, double b,
+                               int64_t top_b, double *running, int64_t n_new_states, double *mean,
+                               double *inv_std, double *sigma_out, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_dir <= 0 || n_dir > INT32_MAX / 4 || world < 1 || chunk < 1 || rows_chunk < 0 ||
+        chunk > INT32_MAX / 4 || rows_chunk > INT32_MAX || (int64_t)world * chunk < n_dir ||
+        n_new_states < 0)
+        return SW_ERR_SIZE;
+    if (!gathered || !deltas || !policy) return SW_ERR_NULL;
+    if (running && (!mean || !inv_std)) return SW_ERR_NULL;
+    const int d = 2 * p->n + 2;
+    const int64_t seg_len = 2 * chunk + rows_chunk * 2 * d;
+    const GatherView gv{gathered, gathered + 2 * chunk, seg_len, (int32_t)chunk,
+                        (int32_t)rows_chunk, world};
+    return launch_update(p, n_dir, gv, deltas, policy, alpha, b, top_b, running, n_new_states,
+                         mean, inv_std, sigma_out, stream);
 }
 
 int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
@@ -996,16 +1053,17 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
 }
 
 int sw_ars_iteration_update_f64(sw_ars_pipeline *pl, int slot, const sw_params *p, int64_t n_dir,
-                                const double *returns, const double *deltas_dev, double *policy,
-                                double alpha, double b, int64_t top_b, const double *moments,
-                                int64_t n_moment_rows, double *running, int64_t n_new_states,
-                                double *mean, double *inv_std, double *sigma_out, void *stream)
+                                const double *gathered, int32_t world, int64_t chunk,
+                                int64_t rows_chunk, const double *deltas_dev, double *policy,
+                                double alpha, double b, int64_t top_b, double *running,
+                                int64_t n_new_states, double *mean, double *inv_std,
+                                double *sigma_out, void *stream)
 {
     if (!pl) return SW_ERR_NULL;
     if (slot < 0 || slot >= SW_PIPELINE_SLOTS) return SW_ERR_SIZE;
-    int rc = sw_ars_update_f64(p, n_dir, returns, deltas_dev, policy, alpha, b, top_b, moments,
-                               n_moment_rows, running, n_new_states, mean, inv_std, sigma_out,
-                               stream);
+    int rc = sw_ars_update_gathered_f64(p, n_dir, gathered, world, chunk, rows_chunk, deltas_dev,
+                                        policy, alpha, b, top_b, running, n_new_states, mean,
+                                        inv_std, sigma_out, stream);
     if (rc) return rc;
     if (hipEventRecord(pl->slot_free[slot], (hipStream_t)stream) != hipSuccess) return SW_ERR_LAUNCH;
     pl->free_valid[slot] = true;

@@ -225,11 +225,12 @@ class ArsPipeline(object):
             ptr(mean), ptr(inv_std), ptr(returns), ptr(traj), ptr(moments), ptr(cov_acc),
             ptr(status), stream_ptr()), "sw_ars_iteration_rollouts_f64")
 
-    def update(self, slot, p, n_dir, returns, deltas_dev, policy, alpha, b, top_b, moments,
-               running, n_new_states, mean, inv_std, sigma_out):
-        n_rows = 0 if moments is None else moments.shape[0]
+    def update(self, slot, p, n_dir, gathered, world, chunk, rows_chunk, deltas_dev, policy,
+               alpha, b, top_b, running, n_new_states, mean, inv_std, sigma_out):
+        """gathered: [world * (2*chunk + rows_chunk*2d)] all-gathered segments (see
+        sw_ars_update_gathered_f64); world = 1: this rank's own segment."""
         check(load().sw_ars_iteration_update_f64(
-            self._h, slot, ctypes.byref(p), n_dir, ptr(returns), ptr(deltas_dev), ptr(policy),
-            float(alpha), float(b), int(top_b), ptr(moments), n_rows, ptr(running),
-            int(n_new_states), ptr(mean), ptr(inv_std), ptr(sigma_out), stream_ptr()),
-            "sw_ars_iteration_update_f64")
+            self._h, slot, ctypes.byref(p), n_dir, ptr(gathered), int(world), int(chunk),
+            int(rows_chunk), ptr(deltas_dev), ptr(policy), float(alpha), float(b), int(top_b),
+            ptr(running), int(n_new_states), ptr(mean), ptr(inv_std), ptr(sigma_out),
+            stream_ptr()), "sw_ars_iteration_update_f64")

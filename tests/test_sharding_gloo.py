@@ -61,3 +61,50 @@ def test_exchange_over_gloo(world, n_dir):
         p.join(120)
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert res == [(r, True) for r in range(world)]
+
+
+def _seg_worker(rank, world, port, n_dir, width, out):
+    from swimmer_amd.ars.sharding import (all_gather_segments, returns_from_segments,
+                                          segment_len)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi, chunk = shard_bounds(n_dir, rank, world)
+        rows_chunk = -(-2 * chunk // 16)
+        L = segment_len(chunk, rows_chunk, width)
+        send = torch.zeros(L, dtype=torch.float64)
+        send[:2 * (hi - lo)] = torch.tensor([_fake_return(i, s) for i in range(lo, hi) for s in (1, -1)],
+                                            dtype=torch.float64)
+        rows_local = -(-2 * (hi - lo) // 16) if hi > lo else 0
+        send[2 * chunk:2 * chunk + rows_local * width] = float(rank + 1)
+        gathered = torch.zeros(world * L, dtype=torch.float64)
+        g = all_gather_segments(send, gathered, world)
+        ra = returns_from_segments(g, n_dir, world, chunk)
+        expect = torch.tensor([_fake_return(i, s) for i in range(n_dir) for s in (1, -1)],
+                              dtype=torch.float64)
+        ok = torch.equal(ra, expect)
+        # the layout the update kernel indexes: segment r at r*L, moments behind 2*chunk returns
+        for r in range(world):
+            rl, rh, _ = shard_bounds(n_dir, r, world)
+            rows_r = -(-2 * (rh - rl) // 16) if rh > rl else 0
+            seg = g[r * L:(r + 1) * L]
+            ok = ok and bool((seg[2 * chunk:2 * chunk + rows_r * width] == r + 1.0).all())
+            ok = ok and bool((seg[2 * chunk + rows_r * width:] == 0.0).all())
+        out.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_dir", [(2, 64), (2, 9), (3, 20)])
+def test_packed_segments_over_gloo(world, n_dir):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seg_worker, args=(r, world, port, n_dir, 16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
