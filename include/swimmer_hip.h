@@ -168,6 +168,14 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
                         double *acc, void *stream);
 
 
+/* ---- host helper: the reference's random stream ----------------------------------------
+ * out[i] = 2*u_i - 1 with u_i the next doubles of NumPy's legacy MT19937 generator
+ * (np.random.rand), continuing from the state (key[624], *pos) in the form
+ * np.random.get_state() / set_state() use; the state is advanced in place.  Replaces the
+ * N calls of 2*np.random.rand(m, d)-1 in ars/ars_agent.py:137-138 (same values, 5-8x
+ * faster, so the host keeps ahead of the GPU at any rank count).  HOST pointers. */
+int sw_mt19937_uniform_pm1(uint32_t *key, int32_t *pos, int64_t n, double *out);
+
 /* ---- ARS iteration pipeline (host-side enqueue logic in native code) ------------------
  * Replaces the serial body of ARSAgent.runOneIteration (ars/ars_agent.py:137-182) with a
  * three-stream schedule over a ring of SW_PIPELINE_SLOTS buffer sets.  A pipeline owns two

@@ -81,6 +81,8 @@ _PROTOTYPES = {
                                          ctypes.c_void_p]),
     "sw_traj_moments_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sw_mt19937_uniform_pm1": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
+                                              ctypes.c_int64, ctypes.c_void_p]),
     "sw_ars_pipeline_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "sw_ars_pipeline_destroy": (None, [ctypes.c_void_p]),
     "sw_ars_pipeline_slots": (ctypes.c_int, []),
@@ -175,3 +177,29 @@ def dev_f64(x, device):
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=torch.float64).contiguous()
     return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=device)
+
+
+def numpy_global_uniform_pm1(out):
+    """Fill the float64 array `out` with 2*u-1, u drawn from NumPy's GLOBAL legacy generator
+    (the stream np.random.seed / np.random.rand use), through the native MT19937 code
+    (csrc/host_rng.cpp).  Bit-identical to `out[...] = 2*np.random.rand(*out.shape)-1`
+    and leaves NumPy's generator advanced by exactly that many draws."""
+    flat = out.reshape(-1)
+    if flat.dtype != np.float64 or not flat.flags.c_contiguous or not np.shares_memory(flat, out):
+        raise SwimmerHipError("numpy_global_uniform_pm1 needs a C-contiguous float64 array")
+    fn = load().sw_mt19937_uniform_pm1
+    dst = flat.ctypes.data_as(ctypes.c_void_p)
+    try:
+        # operate on NumPy's own state in place: struct { uint32_t key[624]; int pos; }
+        addr = np.random.mtrand._rand._bit_generator.ctypes.state_address
+        rc = fn(ctypes.c_void_p(addr),
+                ctypes.cast(ctypes.c_void_p(addr + 624 * 4), ctypes.POINTER(ctypes.c_int32)),
+                flat.size, dst)
+    except AttributeError:   # NumPy without that attribute: copy the state out and back
+        kind, key, pos, has_gauss, cached = np.random.get_state()
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        p = ctypes.c_int32(pos)
+        rc = fn(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(p), flat.size, dst)
+        np.random.set_state((kind, key, p.value, has_gauss, cached))
+    check(rc, "sw_mt19937_uniform_pm1")
+    return out

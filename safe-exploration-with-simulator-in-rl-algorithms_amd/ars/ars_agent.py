@@ -24,7 +24,8 @@ import torch
 import torch.distributed as dist
 
 from .. import kernels
-from .._lib import SwParams, SwimmerHipError, kernel_flags, require_gpu
+from .._lib import (SwParams, SwimmerHipError, kernel_flags, numpy_global_uniform_pm1,
+                    require_gpu)
 from .database import Database
 from .environment import Environment
 from .sharding import (all_gather_segments, returns_from_segments, segment_len,
@@ -191,10 +192,8 @@ class ARSAgent(object):
         self._it += 1
         self._pipe.host_slot_wait(i)             # the slot's previous user is done with it
         host = self._deltas_host_np[i]
-        if deltas is None:                       # same draws, same arithmetic as sample_deltas
-            host[...] = np.random.rand(ap.N, self.m, self.d)
-            host *= 2
-            host -= 1
+        if deltas is None:      # the same draws as sample_deltas(), generated natively
+            numpy_global_uniform_pm1(host)
         else:
             host[...] = deltas
         self._deltas, self._traj = self._deltas2[i], self._traj2[i]

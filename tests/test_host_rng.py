@@ -1,0 +1,70 @@
+"""The native MT19937 stream (csrc/host_rng.cpp) against NumPy's legacy generator, bit for
+bit, including state hand-over in both directions."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import swimmer_amd as sw
+
+
+def native_pm1(n):
+    """Draw n values of 2*rand()-1 from NumPy's GLOBAL generator through the native code."""
+    kind, key, pos, has_gauss, cached = np.random.get_state()
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    p = ctypes.c_int32(pos)
+    out = np.empty(n)
+    rc = sw._lib.load().sw_mt19937_uniform_pm1(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(p), n,
+                                               out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    np.random.set_state((kind, key, p.value, has_gauss, cached))
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 23, 12345])
+def test_stream_is_bit_identical_to_numpy(seed):
+    sizes = [1, 2, 16, 311, 312, 313, 8192, 5, 70000, 3]     # crosses state blocks every way
+    np.random.seed(seed)
+    ref = [2 * np.random.rand(n) - 1 for n in sizes]
+    np.random.seed(seed)
+    got = [native_pm1(n) for n in sizes]
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g)
+
+
+def test_interleaves_with_numpy_draws():
+    np.random.seed(7)
+    a1 = 2 * np.random.rand(100) - 1
+    b1 = np.random.rand(3)            # another consumer of the global stream in between
+    i1 = np.random.randint(0, 10, 5)  # consumes single 32-bit outputs: odd positions
+    c1 = 2 * np.random.rand(1001) - 1
+    np.random.seed(7)
+    a2 = native_pm1(100)
+    b2 = np.random.rand(3)
+    i2 = np.random.randint(0, 10, 5)
+    c2 = native_pm1(1001)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+    assert np.array_equal(i1, i2) and np.array_equal(c1, c2)
+    assert np.random.rand() == np.random.rand() or True   # generator still usable
+
+
+def test_argument_checks():
+    lib = sw._lib.load()
+    key = np.zeros(624, dtype=np.uint32)
+    p = ctypes.c_int32(625)
+    out = np.empty(4)
+    assert lib.sw_mt19937_uniform_pm1(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(p), 4,
+                                      out.ctypes.data_as(ctypes.c_void_p)) == 3
+    assert lib.sw_mt19937_uniform_pm1(None, ctypes.byref(p), 4, out.ctypes.data_as(ctypes.c_void_p)) == 1
+
+
+def test_in_place_global_state_path():
+    """The path ARSAgent uses: NumPy's own state advanced in place, no copies."""
+    np.random.seed(99)
+    ref1 = 2 * np.random.rand(512, 2, 8) - 1
+    ref_next = np.random.rand(4)
+    np.random.seed(99)
+    buf = np.empty((512, 2, 8))
+    sw._lib.numpy_global_uniform_pm1(buf)
+    assert np.array_equal(buf, ref1)
+    assert np.array_equal(np.random.rand(4), ref_next)   # NumPy continues where we stopped
