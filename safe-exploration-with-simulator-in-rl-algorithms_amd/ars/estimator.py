@@ -1,0 +1,96 @@
+"""Simulator-parameter estimator: mirror of the reference `Estimator` objective functions
+(ars/estimator.py:17-87, 112-121).
+
+The reference evaluates its objective I(x) by looping over every stored transition:
+`set_state(s)`, `step(select_action(policy, s))`, compare with the stored next state
+(estimator.py:50-55) -- an embarrassingly parallel batch of single physics steps.  Here all
+transitions of all selected trajectories go through ONE launch of the step kernel
+(sw_step_f64); J(x) is one launch of the rollout kernel.  The CMA-ES search around them
+(estimator.py:89-110) is orchestration and needs the `cma` package, which is optional.
+"""
+import dataclasses
+
+import numpy as np
+import torch
+
+from .. import kernels
+from .._lib import SwParams, require_gpu
+from .parameters import EnvParam
+
+
+class Estimator(object):
+
+    def __init__(self, database, guess_param, capacity, unknowns=('m_i', 'l_i', 'k'),
+                 device="cuda:0"):
+        database.materialize() if hasattr(database, "materialize") else None
+        assert database.size > 0, "Database is empty"
+        assert len(database.trajectories[0]) == guess_param.H, "Rollouts are not the same"
+        self.guess_param = guess_param
+        self.unknowns = unknowns
+        self.database = database
+        self.subset = np.random.randint(0, self.database.size, capacity)   # estimator.py:33
+        self.iter = 0
+        self.device = torch.device(device)
+        self._cache = None
+
+    def convert_to_env_param(self, x):
+        d = dataclasses.asdict(self.guess_param)
+        for i in range(len(self.unknowns)):
+            d[self.unknowns[i]] = x[i]
+        return EnvParam(**d)
+
+    def _params(self, x):
+        ep = self.convert_to_env_param(x)
+        return SwParams.make(ep.n, ep.l_i, ep.m_i, ep.k, ep.h, (1.0, 0.0))
+
+    def _batch(self):
+        """Device copies of the selected trajectories: states [d, T], next states [d, T],
+        actions [m, T] (V1 action a = P s, estimator.py:52), segment lengths."""
+        if self._cache is None:
+            require_gpu()
+            S, Nx, A, lens = [], [], [], []
+            for k in self.subset:
+                P = torch.as_tensor(np.asarray(self.database.policies[k], dtype=np.float64),
+                                    device=self.device)
+                tr = torch.as_tensor(np.asarray(self.database.trajectories[k], dtype=np.float64),
+                                     device=self.device)
+                s, nx = tr[:-1].T.contiguous(), tr[1:].T.contiguous()
+                S.append(s)
+                Nx.append(nx)
+                A.append(P @ s)
+                lens.append(s.shape[1])
+            self._cache = (torch.cat(S, 1).contiguous(), torch.cat(Nx, 1).contiguous(),
+                           torch.cat(A, 1).contiguous(), lens)
+        return self._cache
+
+    def I(self, x):
+        """Sum over stored transitions of || sim_step(s_t, a_t) - s_{t+1} ||_2."""
+        states, nexts, actions, _ = self._batch()
+        sim, _ = kernels.step(self._params(x), states, actions)
+        return float(torch.linalg.vector_norm(sim - nexts, ord=2, dim=0).sum().item())
+
+    def J(self, x):
+        """Deprecated objective of the reference (estimator.py:64-87): whole-rollout distance."""
+        require_gpu()
+        p = self._params(x)
+        dists = []
+        for k in self.subset:
+            P = torch.as_tensor(np.asarray(self.database.policies[k], dtype=np.float64)[None],
+                                device=self.device).contiguous()
+            real = torch.as_tensor(np.asarray(self.database.trajectories[k], dtype=np.float64),
+                                   device=self.device)
+            H = real.shape[0]
+            traj = torch.empty((H, p.d, 1), dtype=torch.float64, device=self.device)
+            kernels.rollout(p, H, P, traj=traj)
+            per_step = torch.linalg.vector_norm(traj[:, :, 0] - real, ord=2, dim=1)
+            dists.append(float((torch.linalg.vector_norm(per_step, ord=2) / H).item()))
+        return float(np.mean(dists))
+
+    def estimate_real_env_param(self):
+        """CMA-ES over I(x) (estimator.py:89-110); needs the optional `cma` package."""
+        import cma
+        d = dataclasses.asdict(self.guess_param)
+        x0 = np.array([d[u] for u in self.unknowns], dtype=np.float64)
+        es = cma.CMAEvolutionStrategy(x0, 1).optimize(self.I)
+        est_x, _, _ = es.best.get()
+        return self.convert_to_env_param(est_x)

@@ -3,7 +3,10 @@
 // Kernels (all fp64, one swimmer / rollout per lane, no MFMA: the largest contraction on
 // this path is 8x8):
 //   step_kernel<N>      one physics step, SoA in / SoA out; HBM-bound at large n_env
-//                       (algorithmic traffic 16 (2n+2) + 8 (n-1) + 8 bytes per env-step)
+//                       (algorithmic traffic 16 (2n+2) + 8 (n-1) + 8 bytes per env-step).
+//                       One env per lane on purpose: a two-envs-per-lane variant with 16-byte
+//                       accesses measured SLOWER at >= 4M envs (4.87 vs 5.62 TB/s: 90 VGPRs,
+//                       5 waves/SIMD, fewer loads in flight per CU) and was dropped.
 //   accel_kernel<N>     accelerations only
 //   rollout_kernel<N,ARS>  H steps with the state, the whitened policy, the return and the
 //                       V2 moment sums held in registers; optional coalesced trajectory

@@ -329,3 +329,65 @@ def test_vec_env_matches_oracle_over_steps(sw):
         assert np.abs(s_dev.T.cpu().numpy() - st).max() <= 1e-11
         assert np.abs(r_dev.cpu().numpy() - rew).max() <= 1e-11
     assert len(env._plans) == 2     # two pre-bound launches (A->B, B->A), reused
+
+
+def test_estimator_objective_is_one_batched_step(sw):
+    """ars/estimator.py:36-62: I(x) over stored transitions, here one step-kernel launch."""
+    from swimmer_amd.ars.estimator import Estimator
+    from swimmer_amd.ars.database import Database
+    H = 60
+    true = sw.EnvParam("real", n=3, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    rng = np.random.RandomState(2)
+    db = Database()
+    op = oracle.OracleParams.make(3, 1.0, 1.0, 10.0, 1e-3)
+    for _ in range(3):
+        P = 0.2 * (2 * rng.rand(2, 8) - 1)
+        _, traj = oracle.rollout(op, H, P, state0=np.r_[0.1, -0.2, rng.uniform(-2, 2, 6)])
+        db.add_trajectory(traj.tolist(), P)
+    np.random.seed(0)
+    est = Estimator(db, sw.EnvParam("guess", n=3, H=H, l_i=1.01, m_i=1.01, h=1e-3, k=10.01,
+                                    epsilon=0.01), capacity=2)
+    assert est.I([1.0, 1.0, 10.0]) < 1e-11          # the reference asserts 0.0 at the true params
+    def ref_I(x):
+        q = oracle.OracleParams.make(3, x[1], x[0], x[2], 1e-3)   # unknowns = (m_i, l_i, k)
+        tot = 0.0
+        for k in est.subset:
+            tr, P = np.array(db.trajectories[k]), db.policies[k]
+            for t in range(H - 1):
+                nxt, _ = oracle.step(q, tr[t], P @ tr[t])
+                tot += np.linalg.norm(nxt - tr[t + 1])
+        return tot
+    for x in ([1.01, 1.01, 10.01], [0.9, 1.2, 9.0]):
+        assert est.I(x) == pytest.approx(ref_I(x), rel=1e-9)
+    assert est.convert_to_env_param([1.5, 0.5, 7.0]) == sw.EnvParam(
+        "guess", n=3, H=H, l_i=0.5, m_i=1.5, h=1e-3, k=7.0, epsilon=0.01)
+    assert est.J([1.0, 1.0, 10.0]) > 1e-3   # rollouts from reset differ from the stored ones
+
+
+def test_large_batch_properties(sw):
+    """A batch too large for the oracle to sweep entirely: sampled oracle check plus
+    whole-batch invariants (theta advances by h*thetadot_old; a sub-batch gives the same bits)."""
+    rng = np.random.default_rng(11)
+    B, n = 1 << 18, 3
+    st = np.empty((8, B))
+    st[0:2] = rng.uniform(-0.5, 0.5, (2, B))
+    st[2::2] = rng.uniform(-np.pi, np.pi, (n, B))
+    st[3::2] = rng.uniform(-2, 2, (n, B))
+    ac = rng.uniform(-5, 5, (2, B))
+    p = sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3)
+    dev = "cuda:0"
+    st_d, ac_d = torch.as_tensor(st, device=dev), torch.as_tensor(ac, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    out, rew = sw.kernels.step(p, st_d, ac_d, status=status)
+    odd = B - 12345
+    out1, rew1 = sw.kernels.step(p, st_d[:, :odd].contiguous(), ac_d[:, :odd].contiguous())
+    assert torch.equal(out[:, :odd], out1) and torch.equal(rew[:odd], rew1)
+    assert int(status.abs().sum()) == 0
+    idx = rng.choice(B, 4096, replace=False)
+    ref, ref_r = oracle.step_batch(oracle.OracleParams.make(n, 0.8, 1.2, 10.2, 1e-3),
+                                   st[:, idx].T.copy(), ac[:, idx].T.copy())
+    assert np.abs(out[:, idx].T.cpu().numpy() - ref).max() <= 1e-12
+    assert np.abs(rew[idx].cpu().numpy() - ref_r).max() <= 1e-12
+    expect_th = st[2::2] + 1e-3 * st[3::2]
+    assert np.abs(out[2::2].cpu().numpy() - expect_th).max() <= 1e-15
+    assert torch.equal(rew, out[0])                      # direction (1, 0): reward = new Gdot_x
