@@ -66,7 +66,8 @@ extern "C" {
 /* sw_params.flags: force one of the two rollout kernels (default: chosen from n and n_roll).
  * Both compute the same rollouts; they differ in summation order only (a few ulp per step). */
 #define SW_FLAG_ROLLOUT_LANE 1 /* one rollout per lane (throughput form, any n) */
-#define SW_FLAG_ROLLOUT_QUAD 2 /* n = 3: one segment per lane, four lanes per rollout (latency form) */
+#define SW_FLAG_ROLLOUT_QUAD 2 /* one segment per lane (latency form): a DPP quad per rollout for
+                                  n = 3, a 16-lane DPP row per rollout for n = 4..8; n = 2 ignores it */
 
 /* Physical parameters of one swimmer model: SwimmerEnv.__init__ (remy_swimmer_env.py:16-39).
  * max_u is not here: the reference never enforces it (actions are not clipped). */

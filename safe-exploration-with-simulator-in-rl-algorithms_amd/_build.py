@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libswimmer_hip.so")
 SOURCES = ["swimmer_kernels.hip", "host_rng.cpp"]
-HEADERS = ["swimmer_device.h", "swimmer_quad3.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
+HEADERS = ["swimmer_device.h", "swimmer_quad3.h", "swimmer_row.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 
 

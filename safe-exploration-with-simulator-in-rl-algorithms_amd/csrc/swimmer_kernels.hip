@@ -26,6 +26,7 @@
 #include "../../include/swimmer_hip.h"
 #include "swimmer_device.h"
 #include "swimmer_quad3.h"
+#include "swimmer_row.h"
 
 namespace {
 
@@ -34,6 +35,8 @@ constexpr int kStepBlock = 256;
 constexpr int kRollBlock = 64;   // one wave per workgroup: every wave gets a SIMD to itself
 constexpr int kMomGroup = 16;    // rollouts per V2 moment row (same partition in every kernel)
 constexpr int64_t kQuadMaxRollouts = 16384;  // above this every SIMD already has a wave
+constexpr int64_t kRowMaxRollouts = 8192;    // row kernel (n >= 4): 4 rollouts per wave
+constexpr int kRowBlock = 256;               // 16 rollouts = one V2 moment row per workgroup
 constexpr int kUpdBlock = 256;
 constexpr double kHalfPi = 1.57079632679489661923;  // math.pi / 2 (remy_swimmer_env.py:65)
 
@@ -462,6 +465,177 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
 }
 
 // ------------------------------------------------------------------------------------
+// n = 4..8, one segment per lane, one rollout per 16-lane DPP row (swimmer_row.h).
+// 256-thread workgroups: 4 waves x 4 rows = 16 rollouts = one V2 moment row.
+template <int N, bool ARS, bool TRAJ, bool MOM>
+__global__ void __launch_bounds__(kRowBlock)
+rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict__ policies,
+                   const double *__restrict__ deltas, int64_t dir_begin, double nu,
+                   const double *__restrict__ mean, const double *__restrict__ inv_std,
+                   const double *__restrict__ state0, double *__restrict__ returns,
+                   double *__restrict__ traj, double *__restrict__ final_state,
+                   double *__restrict__ moments, int32_t *__restrict__ status)
+{
+    constexpr int D = 2 * N + 2, M = N - 1;
+    const int tid = threadIdx.x;
+    const int q = tid & 15;                        // lane inside the row
+    const bool owner = q < N;                      // lanes N..15 mirror lane 0
+    const int seg = owner ? q : 0;
+    const int64_t r_raw = (int64_t)blockIdx.x * kMomGroup + (tid >> 4);
+    const bool valid = r_raw < n_roll;
+    const int64_t r = valid ? r_raw : n_roll - 1;  // surplus rows recompute the last rollout
+    const sw::RowLane<N> L = sw::row_lane<N>(C, seg);
+    const int cth = 2 + 2 * seg, cthd = 3 + 2 * seg;
+
+    // ---- this lane's policy row: V_i = c12 (W_{i-1} - W_i), W = (P +- nu delta) diag(inv_std)
+    // (ars_agent.py:141-142, environment.py:32-34); u_{-1} = u_{n-1} = 0 (free ends)
+    double V[D], mu[D];
+    {
+        const double *pl = ARS ? policies : policies + r * (M * D);
+        const double *dl = ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr;
+        const double sgn = (r & 1) ? -1.0 : 1.0;
+        auto entry = [&](int a, int col) {
+            double w = pl[a * D + col];
+            if (ARS) w = __dadd_rn(w, sgn * __dmul_rn(nu, dl[a * D + col]));
+            if (inv_std) w = __dmul_rn(w, inv_std[col]);
+            return w;
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double up = (seg >= 1) ? entry(seg - 1, j) : 0.0;
+            const double dn = (seg <= M - 1) ? entry(seg, j) : 0.0;
+            V[j] = C.c12 * (up - dn);
+            mu[j] = mean ? mean[j] : 0.0;
+        }
+    }
+
+    // ---- start state ----
+    double gdx = 0.0, gdy = 0.0, th = kHalfPi, thd = 0.0;
+    if (state0) {
+        gdx = state0[r];
+        gdy = state0[n_roll + r];
+        th = state0[(int64_t)cth * n_roll + r];
+        thd = state0[(int64_t)cthd * n_roll + r];
+    }
+    // trajectory cells through a buffer resource; lanes that own no cell get an offset
+    // beyond the buffer, which the hardware range check drops
+    const uint32_t slab = (uint32_t)(D * n_roll * 8);
+    const uint32_t kDrop = 0xfffffff0u;
+    const uint32_t off_th = (owner && valid) ? (uint32_t)(((int64_t)cth * n_roll + r) * 8) : kDrop;
+    const uint32_t off_thd = (owner && valid) ? (uint32_t)(((int64_t)cthd * n_roll + r) * 8) : kDrop;
+    const uint32_t off_g = (q < 2 && valid) ? (uint32_t)(((int64_t)q * n_roll + r) * 8) : kDrop;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        traj, 0, TRAJ ? (int)(uint32_t)((int64_t)H * slab) : 0, 0x00020000);
+    uint32_t soff = 0;
+    auto store_cell = [&](double v, uint32_t voff) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        union { double d; v2i i; } u;
+        u.d = v;
+        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, 0);
+    };
+
+    double total = 0.0, thmax = 0.0, pivmin_all = 1.0;
+    double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
+    for (int32_t t = 0; t < H; ++t) {
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
+        // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean)
+        double thk[N], wk[N];
+        sw::RowGather<N>::run(th, thk);
+        sw::RowGather<N>::run(thd, wk);
+        double tq0 = V[0] * (gdx - mu[0]), tq1 = V[1] * (gdy - mu[1]);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            tq0 = __builtin_fma(V[2 + 2 * k], thk[k] - mu[2 + 2 * k], tq0);
+            tq1 = __builtin_fma(V[3 + 2 * k], wk[k] - mu[3 + 2 * k], tq1);
+        }
+        const double piv = sw::row_step<N>(C, L, gdx, gdy, th, thd, wk, tq0 + tq1);
+        asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(piv));
+        total += __builtin_fma(gdx, C.dirx, gdy * C.diry);
+        const double gsel = __builtin_fma(L.gx, gdx, L.gy * gdy);
+        if (TRAJ) {
+            store_cell(th, off_th);
+            store_cell(thd, off_thd);
+            store_cell(gsel, off_g);
+            soff += slab;
+        }
+        if (MOM) {
+            const double a = th - kHalfPi;
+            m1th += a;
+            m2th = __builtin_fma(a, a, m2th);
+            m1thd += thd;
+            m2thd = __builtin_fma(thd, thd, m2thd);
+            m1g += gsel;
+            m2g = __builtin_fma(gsel, gsel, m2g);
+        }
+    }
+
+    // ---- per-rollout outputs ----
+    {
+        double bad[N], big[N];
+        const bool fin = isfinite(th) && isfinite(thd) && isfinite(gdx) && isfinite(gdy);
+        sw::RowGather<N>::run(fin ? 0.0 : 1.0, bad);
+        sw::RowGather<N>::run(thmax, big);
+        double nbad = 0.0, tmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            nbad += bad[k];
+            tmax = fmax(tmax, big[k]);
+        }
+        const int code = ((pivmin_all > 0.0) ? 0 : SW_STATUS_SINGULAR) |
+                         ((nbad == 0.0) ? 0 : SW_STATUS_NONFINITE) |
+                         ((tmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
+        if (valid && q == 0) {
+            returns[r] = (code & SW_STATUS_RANGE) ? __builtin_nan("") : total;
+            if (status) status[r] = code;
+        }
+    }
+    if (final_state && valid && owner) {
+        final_state[(int64_t)cth * n_roll + r] = th;
+        final_state[(int64_t)cthd * n_roll + r] = thd;
+        if (q < 2) final_state[(int64_t)q * n_roll + r] = (q == 0) ? gdx : gdy;
+    }
+    if (MOM) {
+        __shared__ double shm[kRowBlock / kWave][16][6];
+        if (!valid || !owner) m1th = m2th = m1thd = m2thd = m1g = m2g = 0.0;
+        // sum over the 4 rows of the wave (lane bits 4, 5), then over the 4 waves through LDS
+#pragma unroll
+        for (int off = 16; off < kWave; off <<= 1) {
+            m1th += __shfl_xor(m1th, off, kWave);
+            m2th += __shfl_xor(m2th, off, kWave);
+            m1thd += __shfl_xor(m1thd, off, kWave);
+            m2thd += __shfl_xor(m2thd, off, kWave);
+            m1g += __shfl_xor(m1g, off, kWave);
+            m2g += __shfl_xor(m2g, off, kWave);
+        }
+        const int wv = tid / kWave, ln = tid % kWave;
+        if (ln < 16) {
+            shm[wv][ln][0] = m1th;
+            shm[wv][ln][1] = m2th;
+            shm[wv][ln][2] = m1thd;
+            shm[wv][ln][3] = m2thd;
+            shm[wv][ln][4] = m1g;
+            shm[wv][ln][5] = m2g;
+        }
+        __syncthreads();
+        if (tid < N) {
+            double acc[6];
+#pragma unroll
+            for (int v = 0; v < 6; ++v)
+                acc[v] = (shm[0][tid][v] + shm[1][tid][v]) + (shm[2][tid][v] + shm[3][tid][v]);
+            double *row = moments + (int64_t)blockIdx.x * (2 * D);
+            row[2 + 2 * tid] = acc[0];
+            row[D + 2 + 2 * tid] = acc[1];
+            row[3 + 2 * tid] = acc[2];
+            row[D + 3 + 2 * tid] = acc[3];
+            if (tid < 2) {
+                row[tid] = acc[4];
+                row[D + tid] = acc[5];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 __device__ __forceinline__ double block_sum(double v, double *sh)
 {
 #pragma unroll
@@ -689,6 +863,45 @@ bool use_quad3(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
     return n_roll <= kQuadMaxRollouts;
 }
 
+// n = 4..8: the row (segment-per-lane) kernel while it still finds idle SIMDs.
+bool use_row(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
+{
+    if (p->n < 4) return false;
+    if (p->flags & SW_FLAG_ROLLOUT_LANE) return false;
+    if (with_traj && (int64_t)H * (2 * p->n + 2) * n_roll * 8 >= ((int64_t)1 << 32) - 256) return false;
+    if (n_roll >= ((int64_t)1 << 24)) return false;
+    if (p->flags & SW_FLAG_ROLLOUT_QUAD) return true;
+    return n_roll <= kRowMaxRollouts;
+}
+
+#define SW_LAUNCH_ROW(NN, ARS, HAS_TRAJ, HAS_MOM, STREAM, ...)                                  \
+    do {                                                                                         \
+        if (HAS_TRAJ) {                                                                          \
+            if (HAS_MOM)                                                                         \
+                hipLaunchKernelGGL((rollout_row_kernel<NN, ARS, true, true>), dim3(grid),        \
+                                   dim3(kRowBlock), 0, STREAM, __VA_ARGS__);                     \
+            else                                                                                 \
+                hipLaunchKernelGGL((rollout_row_kernel<NN, ARS, true, false>), dim3(grid),       \
+                                   dim3(kRowBlock), 0, STREAM, __VA_ARGS__);                     \
+        } else {                                                                                 \
+            if (HAS_MOM)                                                                         \
+                hipLaunchKernelGGL((rollout_row_kernel<NN, ARS, false, true>), dim3(grid),       \
+                                   dim3(kRowBlock), 0, STREAM, __VA_ARGS__);                     \
+            else                                                                                 \
+                hipLaunchKernelGGL((rollout_row_kernel<NN, ARS, false, false>), dim3(grid),      \
+                                   dim3(kRowBlock), 0, STREAM, __VA_ARGS__);                     \
+        }                                                                                        \
+    } while (0)
+
+#define SW_DISPATCH_ROW(n, ARS, HAS_TRAJ, HAS_MOM, STREAM, ...)                                 \
+    switch (n) {                                                                                 \
+    case 4: SW_LAUNCH_ROW(4, ARS, HAS_TRAJ, HAS_MOM, STREAM, __VA_ARGS__); break;                \
+    case 5: SW_LAUNCH_ROW(5, ARS, HAS_TRAJ, HAS_MOM, STREAM, __VA_ARGS__); break;                \
+    case 6: SW_LAUNCH_ROW(6, ARS, HAS_TRAJ, HAS_MOM, STREAM, __VA_ARGS__); break;                \
+    case 7: SW_LAUNCH_ROW(7, ARS, HAS_TRAJ, HAS_MOM, STREAM, __VA_ARGS__); break;                \
+    default: SW_LAUNCH_ROW(8, ARS, HAS_TRAJ, HAS_MOM, STREAM, __VA_ARGS__); break;               \
+    }
+
 int launch_status()
 {
     return hipGetLastError() == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
@@ -783,6 +996,13 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
                          moments, status);
         return launch_status();
     }
+    if (use_row(p, n_roll, H, traj != nullptr)) {
+        const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        SW_DISPATCH_ROW(p->n, false, traj != nullptr, moments != nullptr, (hipStream_t)stream, C,
+                        n_roll, H, policies, (const double *)nullptr, (int64_t)0, 0.0, mean,
+                        inv_std, state0, returns, traj, final_state, moments, status);
+        return launch_status();
+    }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
     SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, false>), dim3(grid), dim3(kRollBlock),
                                            0, (hipStream_t)stream, C, n_roll, H, policies,
@@ -810,6 +1030,13 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
                          (hipStream_t)stream, C, n_roll, H, policy, deltas, dir_begin, nu, mean,
                          inv_std, (const double *)nullptr, returns, traj, (double *)nullptr,
                          moments, status);
+        return launch_status();
+    }
+    if (use_row(p, n_roll, H, traj != nullptr)) {
+        const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        SW_DISPATCH_ROW(p->n, true, traj != nullptr, moments != nullptr, (hipStream_t)stream, C,
+                        n_roll, H, policy, deltas, dir_begin, nu, mean, inv_std,
+                        (const double *)nullptr, returns, traj, (double *)nullptr, moments, status);
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);

@@ -109,13 +109,14 @@ def _traj_keys(t):
 
 @pytest.mark.parametrize("kernel", ["lane", "quad"])
 def test_rollouts_vs_reference_golden(sw, golden, kernel):
-    """Both rollout kernels (one rollout per lane / n = 3: one segment per lane)."""
+    """Both rollout kernel families: one rollout per lane ("lane") and one segment per lane
+    ("quad": DPP quad for n = 3, 16-lane DPP row for n = 4..8)."""
     t = golden.trajectories
     worst = 0.0
     for key in _traj_keys(t):
         n = int(key.split("_n")[1][0])
-        if kernel == "quad" and n != 3:
-            continue
+        if kernel == "quad" and n < 3:
+            continue   # segment-per-lane kernels exist for n >= 3 (quad: n = 3, row: n = 4..8)
         l, m, k, h = PARAM_SETS[key.split("_")[2]]
         H = t[key + "_traj"].shape[0]
         ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)
@@ -136,9 +137,10 @@ def test_rollout_batch_vs_oracle_and_moments(sw, kernel):
     """Many different policies at once (ragged last wave), V2 whitening, start states,
     final states and the fused moment sums."""
     rng = np.random.default_rng(5)
-    cases = ((3, 200, 300), (6, 70, 120), (2, 1, 50), (4, 65, 64), (3, 1, 40), (3, 17, 33))
+    cases = ((3, 200, 300), (6, 70, 120), (2, 1, 50), (4, 65, 64), (3, 1, 40), (3, 17, 33),
+             (5, 33, 90), (8, 18, 60), (7, 1, 45))
     for n, R, H in cases:
-        if kernel == "quad" and n != 3:
+        if kernel == "quad" and n < 3:
             continue
         d, m = 2 * n + 2, n - 1
         l, mm, k, h = PARAM_SETS["realworld"]
@@ -233,8 +235,6 @@ def cov_close(c, ref, rel):
 @pytest.mark.parametrize("tag", ARS_CASES)
 def test_ars_iterations_vs_reference_golden(sw, golden, tag, kernel):
     a = golden.ars
-    if kernel == "quad" and "_n3_" not in tag:
-        pytest.skip("the quad kernel is the 3-segment specialisation")
     n, V1, N, b, H, seed, iters = [int(x) for x in a[tag + "_cfg"]]
     l, m, k, h, alpha, nu = [float(x) for x in a[tag + "_phys"]]
     ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)
