@@ -69,11 +69,20 @@ extern "C" {
 #define SW_FLAG_ROLLOUT_QUAD 2 /* one segment per lane (latency form): a DPP quad per rollout for
                                   n = 3, a 16-lane DPP row per rollout for n = 4..8; n = 2 ignores it */
 
+/* sw_params.flags: which of the reference's two swimmer models the kernels integrate.
+ * Default (bit clear): the Gym env (envs/gym_swimmer/swimmer/remy_swimmer_env.py, explicit
+ * Euler, reset = (0, 0, pi/2, 0, ...)).  Bit set: the native RL-Glue environment
+ * (rlglue/environment/SwimmerEnvironment.cpp:102-277: its (5n+2)-unknown formulation with
+ * its quirks, semi-implicit Euler, start state = all 0.001) -- a different numerical model
+ * (they give different accelerations for the same state).  Rollouts of the twin model run on
+ * the lane-per-rollout kernel. */
+#define SW_FLAG_MODEL_TWIN 4
+
 /* Physical parameters of one swimmer model: SwimmerEnv.__init__ (remy_swimmer_env.py:16-39).
  * max_u is not here: the reference never enforces it (actions are not clipped). */
 typedef struct sw_params {
     int32_t n;        /* segments */
-    int32_t flags;    /* 0, or one SW_FLAG_ROLLOUT_* tuning flag */
+    int32_t flags;    /* 0, or SW_FLAG_* bits (rollout kernel choice, model choice) */
     double l_i;       /* segment length */
     double m_i;       /* segment mass */
     double k;         /* viscous friction coefficient */

@@ -33,6 +33,14 @@ int swo_rollout_batch(const swo_params *p, long n_roll, int H, const double *pol
                       const double *mean, const double *cov_diag, double *returns,
                       double *traj);
 
+/* native twin (rlglue/environment/SwimmerEnvironment.cpp), twin_oracle.c */
+int swt_accelerations(const swo_params *p, const double *state, const double *u,
+                      double *gdd, double *tdd);
+int swt_step(const swo_params *p, const double *state, const double *u,
+             double *next, double *reward);
+int swt_step_batch(const swo_params *p, long n_env, const double *states,
+                   const double *actions, double *next, double *rewards);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,9 +28,9 @@ class OracleParams(ctypes.Structure):
 
 def build(force=False):
     """Compile libswimmer_oracle.so with the Makefile next to this file."""
-    src = os.path.join(_HERE, "swimmer_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("swimmer_oracle.c", "twin_oracle.c", "swimmer_oracle.h")]
     if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libswimmer_oracle.so"])
     return _LIB_PATH
 
@@ -50,6 +50,9 @@ def _load():
         lib.swo_rollout.argtypes = [pp, ctypes.c_int, dp, dp, dp, dp, dp, dp]
         lib.swo_step_batch.argtypes = [pp, ctypes.c_long, dp, dp, dp, dp]
         lib.swo_rollout_batch.argtypes = [pp, ctypes.c_long, ctypes.c_int, dp, dp, dp, dp, dp]
+        lib.swt_accelerations.argtypes = [pp, dp, dp, dp, dp]
+        lib.swt_step.argtypes = [pp, dp, dp, dp, dp]
+        lib.swt_step_batch.argtypes = [pp, ctypes.c_long, dp, dp, dp, dp]
         lib.swo_num_threads.restype = ctypes.c_int
         lib.swo_set_num_threads.argtypes = [ctypes.c_int]
         lib.swo_set_num_threads.restype = None
@@ -153,3 +156,29 @@ def rollout_batch(p, H, policies, mean=None, cov=None, want_traj=False):
     _check(_load().swo_rollout_batch(ctypes.byref(p), R, int(H), _p(policies), _p(mean),
                                      _p(cov_diag), _p(rets), _p(traj)))
     return rets, traj
+
+
+# ---- native twin (rlglue/environment/SwimmerEnvironment.cpp), twin_oracle.c ----
+def twin_accelerations(p, state, u):
+    state, u = _c(state), _c(u)
+    gdd = np.empty(2)
+    tdd = np.empty(p.n)
+    _check(_load().swt_accelerations(ctypes.byref(p), _p(state), _p(u), _p(gdd), _p(tdd)))
+    return gdd, tdd
+
+
+def twin_step(p, state, u):
+    state, u = _c(state), _c(u)
+    nxt = np.empty(2 * p.n + 2)
+    r = np.empty(1)
+    _check(_load().swt_step(ctypes.byref(p), _p(state), _p(u), _p(nxt), _p(r)))
+    return nxt, float(r[0])
+
+
+def twin_step_batch(p, states, actions):
+    states, actions = _c(states), _c(actions)
+    B = states.shape[0]
+    nxt = np.empty_like(states)
+    rew = np.empty(B)
+    _check(_load().swt_step_batch(ctypes.byref(p), B, _p(states), _p(actions), _p(nxt), _p(rew)))
+    return nxt, rew

@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libswimmer_hip.so")
 SOURCES = ["swimmer_kernels.hip", "host_rng.cpp"]
-HEADERS = ["swimmer_device.h", "swimmer_quad3.h", "swimmer_row.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
+HEADERS = ["rlglue_env.cpp", os.path.join("..", "..", "include", "rlglue_swimmer.h"),
+           "swimmer_device.h", "swimmer_quad3.h", "swimmer_row.h", "swimmer_twin.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 
 
@@ -26,11 +27,20 @@ def is_stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+RLGLUE_LIB_PATH = os.path.join(CSRC, "librlglue_swimmer_hip.so")
+
+
 def build_library(force=False, verbose=False):
-    """Compile the HIP kernels + C ABI into csrc/libswimmer_hip.so for gfx950."""
-    if not force and not is_stale():
+    """Compile the HIP kernels + C ABI into csrc/libswimmer_hip.so for gfx950, and the
+    RL-Glue environment plug-in (csrc/librlglue_swimmer_hip.so) on top of it."""
+    if not force and not is_stale() and os.path.exists(RLGLUE_LIB_PATH):
         return LIB_PATH
     cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "rlglue_env.cpp"), "-L" + CSRC,
+                                      "-lswimmer_hip", "-Wl,-rpath,$ORIGIN", "-o", RLGLUE_LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -21,7 +21,8 @@ STATUS_SINGULAR = 1
 STATUS_NONFINITE = 2
 STATUS_RANGE = 4
 FLAG_ROLLOUT_LANE = 1   # sw_params.flags: force the lane-per-rollout kernel
-FLAG_ROLLOUT_QUAD = 2   # force the n = 3 segment-per-lane (quad) kernel
+FLAG_ROLLOUT_QUAD = 2   # force the segment-per-lane kernels (quad: n = 3, row: n = 4..8)
+FLAG_MODEL_TWIN = 4     # integrate the native RL-Glue model (SwimmerEnvironment.cpp)
 
 
 class SwParams(ctypes.Structure):

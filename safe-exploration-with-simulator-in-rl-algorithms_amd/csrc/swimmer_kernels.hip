@@ -27,6 +27,7 @@
 #include "swimmer_device.h"
 #include "swimmer_quad3.h"
 #include "swimmer_row.h"
+#include "swimmer_twin.h"
 
 namespace {
 
@@ -39,6 +40,7 @@ constexpr int64_t kRowMaxRollouts = 8192;    // row kernel (n >= 4): 4 rollouts 
 constexpr int kRowBlock = 256;               // 16 rollouts = one V2 moment row per workgroup
 constexpr int kUpdBlock = 256;
 constexpr double kHalfPi = 1.57079632679489661923;  // math.pi / 2 (remy_swimmer_env.py:65)
+constexpr double kTwinStart = 0.001;                // SwimmerEnvironment.cpp:41
 
 sw::Consts make_consts(const sw_params *p)
 {
@@ -54,11 +56,18 @@ sw::Consts make_consts(const sw_params *p)
     return c;
 }
 
+sw::TwinConsts make_twin_consts(const sw_params *p)
+{
+    return sw::TwinConsts{p->l_i, p->m_i, p->k, p->h, p->dir_x, p->dir_y};
+}
+
+inline bool is_twin(const sw_params *p) { return (p->flags & SW_FLAG_MODEL_TWIN) != 0; }
+
 int check_params(const sw_params *p)
 {
     if (!p) return SW_ERR_NULL;
     if (p->n < 2 || p->n > SW_MAX_SEGMENTS) return SW_ERR_SEGMENTS;
-    if (p->flags & ~(SW_FLAG_ROLLOUT_LANE | SW_FLAG_ROLLOUT_QUAD)) return SW_ERR_PARAM;
+    if (p->flags & ~(SW_FLAG_ROLLOUT_LANE | SW_FLAG_ROLLOUT_QUAD | SW_FLAG_MODEL_TWIN)) return SW_ERR_PARAM;
     if (!(p->l_i > 0.0) || !(p->m_i > 0.0) || !isfinite(p->l_i) || !isfinite(p->m_i) ||
         !isfinite(p->k) || !isfinite(p->h) || !isfinite(p->dir_x) || !isfinite(p->dir_y))
         return SW_ERR_PARAM;
@@ -66,9 +75,10 @@ int check_params(const sw_params *p)
 }
 
 // ------------------------------------------------------------------------------------
-template <int N>
+// TWIN selects the reference's native model (swimmer_twin.h) instead of the Gym model.
+template <int N, bool TWIN>
 __global__ void __launch_bounds__(kStepBlock)
-step_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
+step_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_env, const double *__restrict__ sin_,
             const double *__restrict__ act, double *__restrict__ sout,
             double *__restrict__ reward, int32_t *__restrict__ status)
 {
@@ -86,7 +96,8 @@ step_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
     for (int i = 0; i < M; ++i) u[i] = act[(int64_t)i * n_env + e];
     double r;
     const bool in_range = sw::track_angle_range<N>(0.0, th) < sw::kAngleLimit;
-    const bool ok = sw::euler_step<N>(C, gdx, gdy, th, thd, u, r);
+    const bool ok = TWIN ? sw::twin_step<N>(T, gdx, gdy, th, thd, u, r)
+                         : sw::euler_step<N>(C, gdx, gdy, th, thd, u, r);
     if (!in_range) {   // outside sincos_fast's range: NaN out, SW_STATUS_RANGE
         gdx = gdy = r = __builtin_nan("");
 #pragma unroll
@@ -107,9 +118,9 @@ step_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
                     (in_range ? 0 : SW_STATUS_RANGE);
 }
 
-template <int N>
+template <int N, bool TWIN>
 __global__ void __launch_bounds__(kStepBlock)
-accel_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
+accel_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_env, const double *__restrict__ sin_,
              const double *__restrict__ act, double *__restrict__ gdd, double *__restrict__ tdd)
 {
     constexpr int M = N - 1;
@@ -124,7 +135,8 @@ accel_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
     }
 #pragma unroll
     for (int i = 0; i < M; ++i) u[i] = act[(int64_t)i * n_env + e];
-    sw::accelerations<N>(C, gdx, gdy, th, thd, u, ax, ay, a);
+    if (TWIN) sw::accelerations_twin<N>(T, gdx, gdy, th, thd, u, ax, ay, a);
+    else sw::accelerations<N>(C, gdx, gdy, th, thd, u, ax, ay, a);
     if (!(sw::track_angle_range<N>(0.0, th) < sw::kAngleLimit)) {
         ax = ay = __builtin_nan("");
 #pragma unroll
@@ -136,15 +148,17 @@ accel_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_,
     for (int i = 0; i < N; ++i) tdd[(int64_t)i * n_env + e] = a[i];
 }
 
-__global__ void reset_kernel(int n, int64_t n_env, double *__restrict__ state)
+// Gym reset: Gdot = 0, theta = pi/2, thetadot = 0 (remy_swimmer_env.py:64-66); the native
+// twin's env_start sets every observation entry to 0.001 (SwimmerEnvironment.cpp:39-42).
+__global__ void reset_kernel(int n, int twin, int64_t n_env, double *__restrict__ state)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_env) return;
-    state[e] = 0.0;
-    state[n_env + e] = 0.0;
+    state[e] = twin ? kTwinStart : 0.0;
+    state[n_env + e] = twin ? kTwinStart : 0.0;
     for (int i = 0; i < n; ++i) {
-        state[(int64_t)(2 + 2 * i) * n_env + e] = kHalfPi;
-        state[(int64_t)(3 + 2 * i) * n_env + e] = 0.0;
+        state[(int64_t)(2 + 2 * i) * n_env + e] = twin ? kTwinStart : kHalfPi;
+        state[(int64_t)(3 + 2 * i) * n_env + e] = twin ? kTwinStart : 0.0;
     }
 }
 
@@ -154,9 +168,9 @@ __global__ void reset_kernel(int n, int64_t n_env, double *__restrict__ state)
 // P +- nu * delta is built here (ars_agent.py:141-142), so the perturbed policies never
 // exist in HBM.  The V2 whitening P diag(inv_std) (ars/environment.py:32-33) is folded into
 // the register copy of the policy once per rollout instead of once per step.
-template <int N, bool ARS>
+template <int N, bool ARS, bool TWIN>
 __global__ void __launch_bounds__(kRollBlock)
-rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict__ policies,
+rollout_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_roll, int32_t H, const double *__restrict__ policies,
                const double *__restrict__ deltas, int64_t dir_begin, double nu,
                const double *__restrict__ mean, const double *__restrict__ inv_std,
                const double *__restrict__ state0, double *__restrict__ returns,
@@ -215,11 +229,11 @@ rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict
                 thd[i] = state0[(int64_t)(3 + 2 * i) * n_roll + r];
             }
         } else {
-            gdx = gdy = 0.0;
+            gdx = gdy = TWIN ? kTwinStart : 0.0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                th[i] = kHalfPi;
-                thd[i] = 0.0;
+                th[i] = TWIN ? kTwinStart : kHalfPi;
+                thd[i] = TWIN ? kTwinStart : 0.0;
             }
         }
 
@@ -249,7 +263,8 @@ rollout_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict
                 u[i] = a0 + a1;
             }
             double rew;
-            ok = sw::euler_step<N>(C, gdx, gdy, th, thd, u, rew) && ok;
+            ok = (TWIN ? sw::twin_step<N>(T, gdx, gdy, th, thd, u, rew)
+                       : sw::euler_step<N>(C, gdx, gdy, th, thd, u, rew)) && ok;
             total += rew;
             if (traj) {
                 double *tp = traj + (int64_t)t * D * n_roll + r;
@@ -854,7 +869,7 @@ traj_moments_kernel(int64_t n_roll, int32_t H, const double *__restrict__ traj,
 // SIMDs, the lane-per-rollout kernel beyond; sw_params.flags can force either.
 bool use_quad3(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
 {
-    if (p->n != 3) return false;
+    if (p->n != 3 || is_twin(p)) return false;   // segment-per-lane kernels: Gym model only
     if (p->flags & SW_FLAG_ROLLOUT_LANE) return false;
     // the quad kernel addresses the trajectory buffer with 32-bit byte offsets
     if (with_traj && (int64_t)H * 8 * n_roll * 8 >= ((int64_t)1 << 32)) return false;
@@ -866,7 +881,7 @@ bool use_quad3(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
 // n = 4..8: the row (segment-per-lane) kernel while it still finds idle SIMDs.
 bool use_row(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
 {
-    if (p->n < 4) return false;
+    if (p->n < 4 || is_twin(p)) return false;
     if (p->flags & SW_FLAG_ROLLOUT_LANE) return false;
     if (with_traj && (int64_t)H * (2 * p->n + 2) * n_roll * 8 >= ((int64_t)1 << 32) - 256) return false;
     if (n_roll >= ((int64_t)1 << 24)) return false;
@@ -941,7 +956,8 @@ int sw_reset_f64(const sw_params *p, int64_t n_env, double *state, void *stream)
     if (n_env < 0) return SW_ERR_SIZE;
     if (n_env == 0) return SW_OK;
     const unsigned grid = (unsigned)((n_env + 255) / 256);
-    hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p->n, n_env, state);
+    hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p->n,
+                       is_twin(p) ? 1 : 0, n_env, state);
     return launch_status();
 }
 
@@ -955,9 +971,16 @@ int sw_step_f64(const sw_params *p, int64_t n_env, const double *state_in, const
     if (!state_in || !action || !state_out) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
     const unsigned grid = (unsigned)((n_env + kStepBlock - 1) / kStepBlock);
-    SW_DISPATCH_N(p->n, hipLaunchKernelGGL(step_kernel<NN>, dim3(grid), dim3(kStepBlock), 0,
-                                           (hipStream_t)stream, C, n_env, state_in, action,
-                                           state_out, reward, status));
+    const sw::TwinConsts T = make_twin_consts(p);
+    if (is_twin(p)) {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, true>), dim3(grid), dim3(kStepBlock), 0,
+                                               (hipStream_t)stream, C, T, n_env, state_in, action,
+                                               state_out, reward, status));
+    } else {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, false>), dim3(grid), dim3(kStepBlock), 0,
+                                               (hipStream_t)stream, C, T, n_env, state_in, action,
+                                               state_out, reward, status));
+    }
     return launch_status();
 }
 
@@ -971,8 +994,14 @@ int sw_accel_f64(const sw_params *p, int64_t n_env, const double *state, const d
     if (!state || !action || !gdd || !tdd) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
     const unsigned grid = (unsigned)((n_env + kStepBlock - 1) / kStepBlock);
-    SW_DISPATCH_N(p->n, hipLaunchKernelGGL(accel_kernel<NN>, dim3(grid), dim3(kStepBlock), 0,
-                                           (hipStream_t)stream, C, n_env, state, action, gdd, tdd));
+    const sw::TwinConsts T = make_twin_consts(p);
+    if (is_twin(p)) {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((accel_kernel<NN, true>), dim3(grid), dim3(kStepBlock), 0,
+                                               (hipStream_t)stream, C, T, n_env, state, action, gdd, tdd));
+    } else {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((accel_kernel<NN, false>), dim3(grid), dim3(kStepBlock), 0,
+                                               (hipStream_t)stream, C, T, n_env, state, action, gdd, tdd));
+    }
     return launch_status();
 }
 
@@ -1004,10 +1033,20 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
-    SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, false>), dim3(grid), dim3(kRollBlock),
-                                           0, (hipStream_t)stream, C, n_roll, H, policies,
-                                           (const double *)nullptr, (int64_t)0, 0.0, mean, inv_std,
-                                           state0, returns, traj, final_state, moments, status));
+    const sw::TwinConsts T = make_twin_consts(p);
+    if (is_twin(p)) {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, false, true>), dim3(grid),
+                                               dim3(kRollBlock), 0, (hipStream_t)stream, C, T, n_roll, H,
+                                               policies, (const double *)nullptr, (int64_t)0, 0.0, mean,
+                                               inv_std, state0, returns, traj, final_state, moments,
+                                               status));
+    } else {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, false, false>), dim3(grid),
+                                               dim3(kRollBlock), 0, (hipStream_t)stream, C, T, n_roll, H,
+                                               policies, (const double *)nullptr, (int64_t)0, 0.0, mean,
+                                               inv_std, state0, returns, traj, final_state, moments,
+                                               status));
+    }
     return launch_status();
 }
 
@@ -1040,10 +1079,20 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
-    SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, true>), dim3(grid), dim3(kRollBlock),
-                                           0, (hipStream_t)stream, C, n_roll, H, policy, deltas,
-                                           dir_begin, nu, mean, inv_std, (const double *)nullptr,
-                                           returns, traj, (double *)nullptr, moments, status));
+    const sw::TwinConsts T = make_twin_consts(p);
+    if (is_twin(p)) {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, true, true>), dim3(grid),
+                                               dim3(kRollBlock), 0, (hipStream_t)stream, C, T, n_roll, H,
+                                               policy, deltas, dir_begin, nu, mean, inv_std,
+                                               (const double *)nullptr, returns, traj, (double *)nullptr,
+                                               moments, status));
+    } else {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((rollout_kernel<NN, true, false>), dim3(grid),
+                                               dim3(kRollBlock), 0, (hipStream_t)stream, C, T, n_roll, H,
+                                               policy, deltas, dir_begin, nu, mean, inv_std,
+                                               (const double *)nullptr, returns, traj, (double *)nullptr,
+                                               moments, status));
+    }
     return launch_status();
 }
 

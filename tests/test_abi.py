@@ -29,7 +29,9 @@ def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ("sw_step_f64", "sw_rollout_f64", "sw_ars_rollouts_f64", "sw_ars_update_f64",
                  "sw_accel_f64", "sw_reset_f64", "sw_traj_moments_f64", "sw_strerror",
-                 "sw_abi_version"):
+                 "sw_abi_version", "sw_ars_update_gathered_f64", "sw_ars_pipeline_create",
+                 "sw_ars_iteration_rollouts_f64", "sw_ars_iteration_update_f64",
+                 "sw_mt19937_uniform_pm1"):
         assert must in names
 
 
