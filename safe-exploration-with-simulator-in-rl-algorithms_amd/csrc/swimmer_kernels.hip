@@ -684,10 +684,13 @@ __device__ __forceinline__ double ret_at(const GatherView &g, int32_t dir, int s
 }
 
 // used(i): all directions (top_b == 0) or the top_b by max(r+, r-), ties to the higher index
-// (argsort ascending, reversed: ars_agent.py:105-108).
-__device__ __forceinline__ bool dir_used(const GatherView &g, int32_t n_dir, int64_t top_b, int32_t i)
+// (argsort ascending, reversed: ars_agent.py:105-108).  With top_b active every workgroup first
+// stages the N keys in LDS and ranks them there (N^2 / 256 comparisons per thread), leaving a
+// byte mask; directions beyond the LDS capacity fall back to ranking from global memory.
+constexpr int kTopBMaxDirs = 6144;   // 48 KB of keys + 6 KB of flags
+
+__device__ __forceinline__ bool rank_used_global(const GatherView &g, int32_t n_dir, int64_t top_b, int32_t i)
 {
-    if (top_b <= 0 || top_b >= n_dir) return true;
     const double ki = fmax(ret_at(g, i, 0), ret_at(g, i, 1));
     int64_t rank = 0;
     for (int32_t j = 0; j < n_dir; ++j) {
@@ -707,12 +710,32 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                   double *__restrict__ sigma_out)
 {
     __shared__ double sh[kUpdBlock / kWave];
+    __shared__ double keys[kTopBMaxDirs];
+    __shared__ unsigned char flag[kTopBMaxDirs];
     const int e = blockIdx.x;
     if (e < md) {
+        const bool select = top_b > 0 && top_b < n_dir;
+        const bool in_lds = select && n_dir <= kTopBMaxDirs;
+        if (in_lds) {
+            for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+                keys[i] = fmax(ret_at(gv, i, 0), ret_at(gv, i, 1));
+            __syncthreads();
+            for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock) {
+                const double ki = keys[i];
+                int32_t rank = 0;
+                for (int32_t j = 0; j < n_dir; ++j) rank += (keys[j] > ki) || (keys[j] == ki && j > i);
+                flag[i] = rank < top_b;
+            }
+            __syncthreads();
+        }
+        auto dir_used = [&](int32_t i) -> bool {
+            if (!select) return true;
+            return in_lds ? (flag[i] != 0) : rank_used_global(gv, n_dir, top_b, i);
+        };
         // np.std(used_rewards): two-pass, ddof = 0 (ars_agent.py:123)
         double s = 0.0, cnt = 0.0;
         for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
-            if (dir_used(gv, n_dir, top_b, i)) {
+            if (dir_used(i)) {
                 s += ret_at(gv, i, 0) + ret_at(gv, i, 1);
                 cnt += 2.0;
             }
@@ -721,7 +744,7 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         const double mu = s / cnt;
         double v = 0.0, g = 0.0;
         for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
-            if (dir_used(gv, n_dir, top_b, i)) {
+            if (dir_used(i)) {
                 const double rp = ret_at(gv, i, 0), rm = ret_at(gv, i, 1);
                 const double a = rp - mu, c = rm - mu;
                 v += a * a + c * c;
@@ -741,11 +764,24 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         // var = (S2 - S1^2/n)/(n-1) (np.cov, ddof = 1)
         const int j = threadIdx.x;
         if (j < 2 * d) {
-            double a = 0.0;
-            for (int32_t r = 0; r < gv.world; ++r)
-                for (int32_t row = 0; row < gv.rows_chunk; ++row)
-                    a += gv.mom_base[r * gv.seg_len + (int64_t)row * (2 * d) + j];
-            running[1 + j] += a;
+            // eight independent partial sums keep eight loads in flight (a single running sum
+            // serialises one L2 round trip per row: 13 us for 64 rows).  Rows are assigned to
+            // the partial sums by their GLOBAL index (rank-major), so the grouping -- and hence
+            // every bit of the result -- is the same on every rank and for every world size
+            // whose shards are row-aligned.
+            double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const int32_t total = gv.world * gv.rows_chunk;
+            for (int32_t g0 = 0; g0 < total; g0 += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int32_t g = g0 + q;
+                    if (g < total) {
+                        const int32_t r = g / gv.rows_chunk, row = g - r * gv.rows_chunk;
+                        acc[q] += gv.mom_base[r * gv.seg_len + (int64_t)row * (2 * d) + j];
+                    }
+                }
+            }
+            running[1 + j] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         }
         __syncthreads();
         if (j == 0) running[0] += n_new;
