@@ -37,6 +37,12 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+# Instructions one wave issues per env-step in the segment-per-lane rollout kernels (ISA count
+# of the hot loop incl. trajectory stores + moments, scripts/isa_loop_stats.py) and the measured
+# issue interval of a lone wave (profiles/r01_ubench_issue_cost.log: 1.92-2.13 ns per
+# independent instruction of any kind): what actually bounds the latency-bound rollout.
+ROLLOUT_INSTR_PER_STEP = {3: 166, 4: 233, 6: 332}
+LONE_WAVE_NS_PER_INSTR = 1.95   # fastest observed mix (v_mov_b64 1.92, f64 + SALU 1.98, f64 FMA 2.13)
 
 
 def parse():
@@ -60,6 +66,18 @@ def pmc_traffic(kernel, n, directions, H):
     if not os.path.exists(path) or (n, directions, H) != (3, 512, 1000):
         return None
     return json.load(open(path)).get(kernel, {}).get("traffic_bytes")
+
+
+def issue_bound(n, H, kern_ms):
+    """The rollout kernel's real ceiling: every wave runs alone on its SIMD and can issue one
+    instruction per ~2.1 ns, so a rollout batch cannot finish faster than
+    H x instructions-per-step x that interval, whatever the batch size."""
+    if n not in ROLLOUT_INSTR_PER_STEP:
+        return None
+    floor_ms = H * ROLLOUT_INSTR_PER_STEP[n] * LONE_WAVE_NS_PER_INSTR * 1e-6
+    return {"instructions_per_step": ROLLOUT_INSTR_PER_STEP[n],
+            "lone_wave_ns_per_instruction": LONE_WAVE_NS_PER_INSTR,
+            "floor_ms": floor_ms, "frac": floor_ms / kern_ms}
 
 
 def cpu_baseline(n, H, directions, seconds):
@@ -198,13 +216,15 @@ def main():
                                                 args.directions, H),
                          "algorithmic_bytes": alg_bytes,
                          "kernel": ("rollout_quad3_kernel<true,true,true>" if n == 3
-                                    else f"rollout_kernel<{n},true>"),
+                                    else f"rollout_row_kernel<{n},true,true,true>" if n >= 4
+                                    else f"rollout_kernel<{n},true,false>"),
                          "kernel_ms": kern_ms,
                          "note": "the fused rollout is fp64-VALU-latency bound by construction "
                                  "(state, policy and sums stay in registers); HBM is the "
                                  "contract's roofline, see DESIGN.md and aux.step_only",
                          "fp64_tflops": local_steps * flops_per_step / (kern_ms * 1e-3) / 1e12,
-                         "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
+                         "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                         "issue_bound": issue_bound(n, H, kern_ms)},
         }
         if not args.no_aux:
             line["aux"] = {"step_only": aux_step_only(sw, n, device)}
