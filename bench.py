@@ -145,11 +145,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
                              "(one process per GPU)")
+    # Rehearsal knobs (never set by the driver): run the multi-rank code path on a one-GPU box,
+    # every rank on cuda:0 with gloo staged through the host instead of RCCL.
+    backend = os.environ.get("SWIMMER_BENCH_BACKEND", "nccl")
+    if os.environ.get("SWIMMER_BENCH_SINGLE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     import swimmer_amd as sw
     sw._lib.load()
@@ -179,9 +187,16 @@ def main():
     kern_ms, kern_launches = agent._pipe.rollout_ms()
     agent._pipe.timing(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank must hold the same policy (redundant deterministic update)
+        pol = torch.as_tensor(agent.policy)
+        ref = pol.clone() if backend != "nccl" else pol.to(device)
+        mine = ref.clone()
+        dist.broadcast(ref, src=0)
+        if not torch.equal(ref, mine):
+            raise SystemExit(f"rank {rank}: policy differs from rank 0 after {args.steps} iterations")
     bad = int((agent._status != 0).sum().item())
     if bad or not np.isfinite(agent.policy).all():
         raise SystemExit(f"bench produced {bad} bad rollouts / non-finite policy")
