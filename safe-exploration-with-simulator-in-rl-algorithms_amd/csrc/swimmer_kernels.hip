@@ -29,6 +29,12 @@
 #include "swimmer_row.h"
 #include "swimmer_twin.h"
 
+// cache policy of the trajectory stores of the segment-per-lane kernels (gfx940+ encoding:
+// 1 = sc0, 2 = nt, 16 = sc1); see DESIGN.md for the measurement behind the choice
+#ifndef SW_TRAJ_STORE_AUX
+#define SW_TRAJ_STORE_AUX 0
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -402,7 +408,7 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         typedef int v2i __attribute__((ext_vector_type(2)));
         union { double d; v2i i; } u;
         u.d = v;
-        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
     };
 
     double total = 0.0, thmax = 0.0, detmin = 1.0;
@@ -546,7 +552,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         typedef int v2i __attribute__((ext_vector_type(2)));
         union { double d; v2i i; } u;
         u.d = v;
-        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
     };
 
     double total = 0.0, thmax = 0.0, pivmin_all = 1.0;
@@ -701,7 +707,12 @@ __device__ __forceinline__ bool rank_used_global(const GatherView &g, int32_t n_
 }
 
 // grid = m*d + 1 workgroups.  Workgroup e < m*d updates policy entry e; the last one merges
-// the V2 statistics.  Every workgroup recomputes sigma_R (2 n_dir values, L2-resident).
+// the V2 statistics.  The kernel sits on the critical path between two rollout launches and
+// is pure latency, so every workgroup first pulls what it needs with ONE round of loads (the
+// 2 n_dir returns and its delta column into LDS / registers; all moment rows in parallel) and
+// then only touches LDS: ~5 us instead of ~17 us for the load-then-use-per-pass version.
+constexpr int kUpdMaxDirs = kTopBMaxDirs;
+
 __global__ void __launch_bounds__(kUpdBlock)
 ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                   const double *__restrict__ deltas, double *__restrict__ policy, double alpha,
@@ -710,24 +721,41 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                   double *__restrict__ sigma_out)
 {
     __shared__ double sh[kUpdBlock / kWave];
-    __shared__ double keys[kTopBMaxDirs];
-    __shared__ unsigned char flag[kTopBMaxDirs];
+    __shared__ double rp_s[kUpdMaxDirs], rm_s[kUpdMaxDirs];   // r+ and r- of every direction
+    __shared__ unsigned char flag[kUpdMaxDirs];
     const int e = blockIdx.x;
     if (e < md) {
         const bool select = top_b > 0 && top_b < n_dir;
-        const bool in_lds = select && n_dir <= kTopBMaxDirs;
+        const bool in_lds = n_dir <= kUpdMaxDirs;
+        // one round of global loads: returns -> LDS, this workgroup's delta column -> registers
+        constexpr int kMaxPer = (kUpdMaxDirs + kUpdBlock - 1) / kUpdBlock;
+        double dcol[kMaxPer];
         if (in_lds) {
-            for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
-                keys[i] = fmax(ret_at(gv, i, 0), ret_at(gv, i, 1));
-            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kMaxPer; ++q) {
+                const int32_t i = threadIdx.x + q * kUpdBlock;
+                dcol[q] = (i < n_dir) ? deltas[(int64_t)i * md + e] : 0.0;
+            }
             for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock) {
-                const double ki = keys[i];
-                int32_t rank = 0;
-                for (int32_t j = 0; j < n_dir; ++j) rank += (keys[j] > ki) || (keys[j] == ki && j > i);
-                flag[i] = rank < top_b;
+                rp_s[i] = ret_at(gv, i, 0);
+                rm_s[i] = ret_at(gv, i, 1);
             }
             __syncthreads();
+            if (select) {
+                for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock) {
+                    const double ki = fmax(rp_s[i], rm_s[i]);
+                    int32_t rank = 0;
+                    for (int32_t j = 0; j < n_dir; ++j) {
+                        const double kj = fmax(rp_s[j], rm_s[j]);
+                        rank += (kj > ki) || (kj == ki && j > i);
+                    }
+                    flag[i] = rank < top_b;
+                }
+                __syncthreads();
+            }
         }
+        auto rplus = [&](int32_t i) { return in_lds ? rp_s[i] : ret_at(gv, i, 0); };
+        auto rminus = [&](int32_t i) { return in_lds ? rm_s[i] : ret_at(gv, i, 1); };
         auto dir_used = [&](int32_t i) -> bool {
             if (!select) return true;
             return in_lds ? (flag[i] != 0) : rank_used_global(gv, n_dir, top_b, i);
@@ -736,20 +764,33 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         double s = 0.0, cnt = 0.0;
         for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
             if (dir_used(i)) {
-                s += ret_at(gv, i, 0) + ret_at(gv, i, 1);
+                s += rplus(i) + rminus(i);
                 cnt += 2.0;
             }
         s = block_sum(s, sh);
         cnt = block_sum(cnt, sh);
         const double mu = s / cnt;
         double v = 0.0, g = 0.0;
-        for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
-            if (dir_used(i)) {
-                const double rp = ret_at(gv, i, 0), rm = ret_at(gv, i, 1);
-                const double a = rp - mu, c = rm - mu;
-                v += a * a + c * c;
-                g = __builtin_fma(rp - rm, deltas[(int64_t)i * md + e], g);
+        if (in_lds) {
+#pragma unroll   // static index into dcol[] (a runtime index would send it to scratch)
+            for (int q = 0; q < kMaxPer; ++q) {
+                const int32_t i = threadIdx.x + q * kUpdBlock;
+                if (i < n_dir && dir_used(i)) {
+                    const double rp = rp_s[i], rm = rm_s[i];
+                    const double a = rp - mu, c = rm - mu;
+                    v += a * a + c * c;
+                    g = __builtin_fma(rp - rm, dcol[q], g);
+                }
             }
+        } else {
+            for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+                if (dir_used(i)) {
+                    const double rp = rplus(i), rm = rminus(i);
+                    const double a = rp - mu, c = rm - mu;
+                    v += a * a + c * c;
+                    g = __builtin_fma(rp - rm, deltas[(int64_t)i * md + e], g);
+                }
+        }
         v = block_sum(v, sh);
         g = block_sum(g, sh);
         if (threadIdx.x == 0) {
@@ -759,40 +800,44 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
             if (e == 0 && sigma_out) *sigma_out = sigma;
         }
     } else if (running != nullptr) {
-        // V2: merge this iteration's partial sums (rank-major, row by row: a fixed order that
-        // is the same on every rank) into the running sums, then mean = c + S1/n,
-        // var = (S2 - S1^2/n)/(n-1) (np.cov, ddof = 1)
-        const int j = threadIdx.x;
+        // V2: merge this iteration's partial sums into the running sums, then
+        // mean = c + S1/n, var = (S2 - S1^2/n)/(n-1) (np.cov, ddof = 1).
+        // Thread (rg, j) = (tid / 64, tid % 64) sums column j over the rows whose GLOBAL index
+        // (rank-major) is congruent to rg mod 4, in ascending order with eight loads in flight;
+        // the four partial sums are combined in a fixed tree.  Global row indices make the
+        // grouping -- and every bit of the result -- independent of the world size for
+        // row-aligned shards, and identical on every rank.
+        __shared__ double part[kUpdBlock / kWave][kWave];
+        const int j = threadIdx.x & 63, rg = threadIdx.x >> 6;
+        const int32_t total = gv.world * gv.rows_chunk;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
         if (j < 2 * d) {
-            // eight independent partial sums keep eight loads in flight (a single running sum
-            // serialises one L2 round trip per row: 13 us for 64 rows).  Rows are assigned to
-            // the partial sums by their GLOBAL index (rank-major), so the grouping -- and hence
-            // every bit of the result -- is the same on every rank and for every world size
-            // whose shards are row-aligned.
-            double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            const int32_t total = gv.world * gv.rows_chunk;
-            for (int32_t g0 = 0; g0 < total; g0 += 8) {
+            for (int32_t g0 = rg; g0 < total; g0 += 16) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int32_t g = g0 + q;
+                for (int q = 0; q < 4; ++q) {
+                    const int32_t g = g0 + 4 * q;
                     if (g < total) {
                         const int32_t r = g / gv.rows_chunk, row = g - r * gv.rows_chunk;
                         acc[q] += gv.mom_base[r * gv.seg_len + (int64_t)row * (2 * d) + j];
                     }
                 }
             }
-            running[1 + j] += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         }
+        part[rg][j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
-        if (j == 0) running[0] += n_new;
+        if (rg == 0 && j < 2 * d)
+            running[1 + j] += (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
         __syncthreads();
-        if (j < d) {
+        if (threadIdx.x == 0) running[0] += n_new;
+        __syncthreads();
+        if (threadIdx.x < d) {
+            const int c_ = threadIdx.x;
             const double n = running[0];
-            const double s1 = running[1 + j], s2 = running[1 + d + j];
-            const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
-            mean[j] = c + s1 / n;
+            const double s1 = running[1 + c_], s2 = running[1 + d + c_];
+            const double c = (c_ >= 2 && (c_ & 1) == 0) ? kHalfPi : 0.0;
+            mean[c_] = c + s1 / n;
             const double var = (s2 - s1 * (s1 / n)) / (n - 1.0);
-            inv_std[j] = 1.0 / sqrt(var);                    // diag(cov) ** -0.5
+            inv_std[c_] = 1.0 / sqrt(var);                   // diag(cov) ** -0.5
         }
     }
 }
