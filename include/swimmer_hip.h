@@ -211,7 +211,8 @@ void sw_ars_pipeline_destroy(sw_ars_pipeline *pl);
 int sw_ars_pipeline_slots(void);
 int sw_ars_pipeline_host_slot_wait(sw_ars_pipeline *pl, int slot);
 int sw_ars_pipeline_sync_cov(sw_ars_pipeline *pl);
-/* enable != 0: record HIP events around every rollout launch on its stream (resets the log) */
+/* enable = k > 0: record HIP events around every k-th rollout launch on its stream (resets the
+ * log; each timed launch costs ~10 us of pipeline bubbles, so sample sparsely); 0: off */
 int sw_ars_pipeline_timing(sw_ars_pipeline *pl, int enable);
 int sw_ars_pipeline_rollout_ms(sw_ars_pipeline *pl, double *mean_ms, int64_t *launches);
 

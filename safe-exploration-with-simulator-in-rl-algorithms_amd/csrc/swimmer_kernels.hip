@@ -1261,8 +1261,9 @@ struct sw_ars_pipeline {
                cov_done[SW_PIPELINE_SLOTS] = {}, rolled = nullptr;
     bool h2d_valid[SW_PIPELINE_SLOTS] = {}, free_valid[SW_PIPELINE_SLOTS] = {},
          cov_valid[SW_PIPELINE_SLOTS] = {};
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // around each rollout launch
+    int timing = 0;                                        // 0 off, k: time every k-th launch
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // around the sampled rollout launches
     const double *cov_traj = nullptr;                      // covariance pass owed for this slot
     double *cov_acc = nullptr;
     int64_t cov_rolls = 0;
@@ -1334,7 +1335,8 @@ int sw_ars_pipeline_sync_cov(sw_ars_pipeline *pl)
 int sw_ars_pipeline_timing(sw_ars_pipeline *pl, int enable)
 {
     if (!pl) return SW_ERR_NULL;
-    pl->timing = enable != 0;
+    pl->timing = enable > 0 ? enable : 0;
+    pl->launches = 0;
     if (enable) {
         for (auto &e : pl->timed) {
             (void)hipEventDestroy(e.first);
@@ -1388,14 +1390,15 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
         return SW_ERR_LAUNCH;
     if (n_dir > 0) {
         std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-        if (pl->timing) {
+        const bool timed_launch = pl->timing > 0 && (pl->launches++ % pl->timing) == 0;
+        if (timed_launch) {
             if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess ||
                 hipEventRecord(ev.first, main) != hipSuccess)
                 return SW_ERR_LAUNCH;
         }
         rc = sw_ars_rollouts_f64(p, dir_begin, n_dir, H, policy, deltas_dev, nu, mean, inv_std,
                                  returns, traj, moments, status, stream);
-        if (pl->timing) {
+        if (timed_launch) {
             (void)hipEventRecord(ev.second, main);
             pl->timed.push_back(ev);
         }

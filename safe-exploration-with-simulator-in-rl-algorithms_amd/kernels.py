@@ -205,8 +205,9 @@ class ArsPipeline(object):
     def sync_cov(self):
         check(load().sw_ars_pipeline_sync_cov(self._h), "sw_ars_pipeline_sync_cov")
 
-    def timing(self, enable):
-        check(load().sw_ars_pipeline_timing(self._h, 1 if enable else 0), "sw_ars_pipeline_timing")
+    def timing(self, every):
+        """every = k > 0: HIP events around every k-th rollout launch; 0 / False: off."""
+        check(load().sw_ars_pipeline_timing(self._h, int(every)), "sw_ars_pipeline_timing")
 
     def rollout_ms(self):
         ms, n = ctypes.c_double(), ctypes.c_int64()

@@ -11,12 +11,12 @@ def run(N=512, H=1000, K=40, **kw):
     fixed = agent.sample_deltas() if os.environ.get("FIXED_DELTAS") else None
     for _ in range(5): agent.run_iteration_async(fixed)
     torch.cuda.synchronize()
-    agent._pipe.timing(True)
+    agent._pipe.timing(0 if os.environ.get("NO_TIMING") else int(os.environ.get("TIME_EVERY", "1")))
     t0 = time.perf_counter()
     for _ in range(K): agent.run_iteration_async(fixed)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
-    ms, n = agent._pipe.rollout_ms()
+    ms, n = agent._pipe.rollout_ms() if not os.environ.get("NO_TIMING") else (0.0, 0)
     return dt * 1e3, ms
 
 MODES = (("v2 full cov", {}), ("v2 diag only", dict(full_covariance=False)), ("v1", dict(V1=True)),
