@@ -45,6 +45,7 @@ constexpr int64_t kQuadMaxRollouts = 16384;  // above this every SIMD already ha
 constexpr int64_t kRowMaxRollouts = 8192;    // row kernel (n >= 4): 4 rollouts per wave
 constexpr int kRowBlock = 256;               // 16 rollouts = one V2 moment row per workgroup
 constexpr int kUpdBlock = 256;
+constexpr int64_t kStepStreamBytes = (int64_t)256 << 20;   // beyond the Infinity Cache: nontemporal accesses
 constexpr double kHalfPi = 1.57079632679489661923;  // math.pi / 2 (remy_swimmer_env.py:65)
 constexpr double kTwinStart = 0.001;                // SwimmerEnvironment.cpp:41
 
@@ -82,7 +83,22 @@ int check_params(const sw_params *p)
 
 // ------------------------------------------------------------------------------------
 // TWIN selects the reference's native model (swimmer_twin.h) instead of the Gym model.
-template <int N, bool TWIN>
+// NT = nontemporal loads and stores: for batches that stream through HBM (larger than the
+// 256 MiB Infinity Cache) they measured +6..8 % (16.8 M envs: 5.91 -> 6.37 TB/s); smaller
+// batches keep plain accesses so that a step loop stays cache resident.
+template <bool NT> __device__ __forceinline__ double ld_f64(const double *p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT> __device__ __forceinline__ void st_f64(double v, double *p)
+{
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+#define SW_LD(p) ld_f64<NT>(p)
+#define SW_ST(v, p) st_f64<NT>(v, p)
+
+template <int N, bool TWIN, bool NT>
 __global__ void __launch_bounds__(kStepBlock)
 step_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_env, const double *__restrict__ sin_,
             const double *__restrict__ act, double *__restrict__ sout,
@@ -91,15 +107,15 @@ step_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_env, const double *__restr
     constexpr int M = N - 1;
     const int64_t e = (int64_t)blockIdx.x * kStepBlock + threadIdx.x;
     if (e >= n_env) return;
-    double gdx = sin_[e], gdy = sin_[n_env + e];
+    double gdx = SW_LD(&sin_[e]), gdy = SW_LD(&sin_[n_env + e]);
     double th[N], thd[N], u[M];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        th[i] = sin_[(int64_t)(2 + 2 * i) * n_env + e];
-        thd[i] = sin_[(int64_t)(3 + 2 * i) * n_env + e];
+        th[i] = SW_LD(&sin_[(int64_t)(2 + 2 * i) * n_env + e]);
+        thd[i] = SW_LD(&sin_[(int64_t)(3 + 2 * i) * n_env + e]);
     }
 #pragma unroll
-    for (int i = 0; i < M; ++i) u[i] = act[(int64_t)i * n_env + e];
+    for (int i = 0; i < M; ++i) u[i] = SW_LD(&act[(int64_t)i * n_env + e]);
     double r;
     const bool in_range = sw::track_angle_range<N>(0.0, th) < sw::kAngleLimit;
     const bool ok = TWIN ? sw::twin_step<N>(T, gdx, gdy, th, thd, u, r)
@@ -109,16 +125,16 @@ step_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_env, const double *__restr
 #pragma unroll
         for (int i = 0; i < N; ++i) th[i] = thd[i] = __builtin_nan("");
     }
-    sout[e] = gdx;
-    sout[n_env + e] = gdy;
+    SW_ST(gdx, &sout[e]);
+    SW_ST(gdy, &sout[n_env + e]);
     bool fin = isfinite(gdx) && isfinite(gdy);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        sout[(int64_t)(2 + 2 * i) * n_env + e] = th[i];
-        sout[(int64_t)(3 + 2 * i) * n_env + e] = thd[i];
+        SW_ST(th[i], &sout[(int64_t)(2 + 2 * i) * n_env + e]);
+        SW_ST(thd[i], &sout[(int64_t)(3 + 2 * i) * n_env + e]);
         fin = fin && isfinite(th[i]) && isfinite(thd[i]);
     }
-    if (reward) reward[e] = r;
+    if (reward) SW_ST(r, &reward[e]);
     if (status)
         status[e] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE) |
                     (in_range ? 0 : SW_STATUS_RANGE);
@@ -1053,12 +1069,18 @@ int sw_step_f64(const sw_params *p, int64_t n_env, const double *state_in, const
     const sw::Consts C = make_consts(p);
     const unsigned grid = (unsigned)((n_env + kStepBlock - 1) / kStepBlock);
     const sw::TwinConsts T = make_twin_consts(p);
+    const int d = 2 * p->n + 2;
+    const bool nt = n_env * (int64_t)(8 * (2 * d + p->n)) > kStepStreamBytes;
     if (is_twin(p)) {
-        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, true>), dim3(grid), dim3(kStepBlock), 0,
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, true, false>), dim3(grid), dim3(kStepBlock), 0,
+                                               (hipStream_t)stream, C, T, n_env, state_in, action,
+                                               state_out, reward, status));
+    } else if (nt) {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, false, true>), dim3(grid), dim3(kStepBlock), 0,
                                                (hipStream_t)stream, C, T, n_env, state_in, action,
                                                state_out, reward, status));
     } else {
-        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, false>), dim3(grid), dim3(kStepBlock), 0,
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, false, false>), dim3(grid), dim3(kStepBlock), 0,
                                                (hipStream_t)stream, C, T, n_env, state_in, action,
                                                state_out, reward, status));
     }

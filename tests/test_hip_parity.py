@@ -391,3 +391,9 @@ def test_large_batch_properties(sw):
     expect_th = st[2::2] + 1e-3 * st[3::2]
     assert np.abs(out[2::2].cpu().numpy() - expect_th).max() <= 1e-15
     assert torch.equal(rew, out[0])                      # direction (1, 0): reward = new Gdot_x
+    # beyond 256 MiB of traffic the launcher switches to nontemporal loads/stores: same bits
+    reps = 8                                             # 2^21 envs: 319 MB per launch
+    big_s, big_a = st_d.repeat(1, reps).contiguous(), ac_d.repeat(1, reps).contiguous()
+    out_nt, rew_nt = sw.kernels.step(p, big_s, big_a)
+    assert torch.equal(out_nt[:, :B], out) and torch.equal(out_nt[:, -B:], out)
+    assert torch.equal(rew_nt[B:2 * B], rew)
