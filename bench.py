@@ -245,9 +245,10 @@ def main():
                          "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                          "issue_bound": issue_bound(n, H, kern_ms)},
         }
-        if not args.no_aux:
+        # the step-only sweep and the CPU baseline belong to the N = 1 line only
+        if not args.no_aux and world == 1:
             line["aux"] = {"step_only": aux_step_only(sw, n, device)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, H, args.directions, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
