@@ -297,12 +297,11 @@ class ARSAgent(object):
             rewards.append(r)
             if j % 10 == 0:
                 if self.rank == 0:
-                    print(f"Seed {self.n_seed} ------ V1 = {self.agent_param.V1}; "
-                          f"n={self.real_env_param.n}; h={self.real_env_param.h}; "
-                          f"alpha={self.agent_param.alpha}; nu={self.agent_param.nu}; "
-                          f"N={self.agent_param.N}; b={self.agent_param.b}; "
-                          f"m_i={self.real_env_param.m_i}; l_i={self.real_env_param.l_i} "
-                          f"------ Iteration {j}/{self.agent_param.n_iter}: {r}")
+                    ap, ep = self.agent_param, self.real_env_param
+                    variant = "V1" if ap.V1 else "V2"
+                    print(f"[seed {self.n_seed}] ARS {variant} n={ep.n} N={ap.N} b={ap.b} "
+                          f"alpha={ap.alpha} nu={ap.nu} h={ep.h} l_i={ep.l_i} m_i={ep.m_i} | "
+                          f"iteration {j}/{ap.n_iter}: mean return {r}")
                 if save_data_path is not None and self.rank == 0:
                     self.database.save(save_data_path)
         self.real_world.close()

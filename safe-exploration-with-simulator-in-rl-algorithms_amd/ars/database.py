@@ -1,9 +1,15 @@
-"""Trajectory store: mirror of the reference `Database` (ars/database.py:8-37).
+"""Trajectory store.
 
-Same attributes (`policies`, `trajectories`, `size`) and the same .npz format
-(`policies`, `trajectories` arrays; np.savez, database.py:37).  Trajectories produced by
-the rollout kernel arrive as one device tensor [H, d, n_roll] per iteration; they are kept
-on the GPU and only transposed to the reference's [rollout][t][d] order when read.
+Drop-in for the reference's `Database` (ars/database.py:8-37): the same public attributes
+(`policies`, `trajectories`, `size`), the same methods (`load`, `add_trajectory`, `save`) and
+the same on-disk format -- one .npz holding the arrays `policies` [R, m, d] and
+`trajectories` [R, H, d] (database.py:37).
+
+What differs is where rollouts live before anyone looks at them: the rollout kernel produces
+one device tensor [H, d, R] per iteration, and copying 65 MB to the host after every ARS
+iteration would cost more than the iteration.  `add_device_batch` therefore only keeps a
+reference to the device tensor; the transposition to the reference's per-rollout host lists
+happens lazily, when `policies` / `trajectories` are read or the store is saved.
 """
 import numpy as np
 
@@ -11,46 +17,54 @@ import numpy as np
 class Database(object):
 
     def __init__(self):
-        self.policies = []
-        self.trajectories = []
+        self._policies = []
+        self._trajectories = []
+        self._device_batches = []   # (traj [H, d, R] device tensor, policies [R, m, d] host array)
         self.size = 0
-        self._pending = []  # (traj [H, d, R] device tensor, policies [R, m, d] host array)
 
-    def _flush(self):
-        for traj, pols in self._pending:
-            host = traj.permute(2, 0, 1).contiguous().cpu().numpy()  # [R, H, d]
-            for r in range(host.shape[0]):
-                self.trajectories.append(host[r].tolist())
-                self.policies.append(np.array(pols[r]))
-        self._pending = []
+    # ---- lazily materialised views --------------------------------------------------
+    def materialize(self):
+        """Move every pending device batch into the host lists (rollout-major, [t][field])."""
+        batches, self._device_batches = self._device_batches, []
+        for traj, pols in batches:
+            per_rollout = traj.permute(2, 0, 1).contiguous().cpu().numpy()
+            for r, states in enumerate(per_rollout):
+                self._trajectories.append(states.tolist())
+                self._policies.append(np.array(pols[r]))
+        return self
 
-    def load(self, path):
-        npzfile = np.load(path)
-        assert ('policies' in npzfile.files and 'trajectories' in npzfile.files), \
-            "The file loaded doesn't contain the array 'policies' and 'trajectories'"
-        policies = npzfile['policies']
-        trajectories = npzfile['trajectories']
-        assert (len(policies) == len(trajectories)), \
-            "'policies' and 'trajectories' doesn't have the same length"
-        for policy, trajectory in zip(policies, trajectories):
-            self.add_trajectory(trajectory, policy)
+    @property
+    def policies(self):
+        return self.materialize()._policies
 
+    @property
+    def trajectories(self):
+        return self.materialize()._trajectories
+
+    # ---- the reference's interface ----------------------------------------------------
     def add_trajectory(self, trajectory, policy):
-        self._flush()
-        self.trajectories.append(trajectory)
-        self.policies.append(policy)
+        self.materialize()
+        self._trajectories.append(trajectory)
+        self._policies.append(policy)
         self.size += 1
 
     def add_device_batch(self, traj, policies):
-        """traj [H, d, R] device tensor (kept as is), policies [R, m, d] host array."""
-        self._pending.append((traj, policies))
+        """All rollouts of one kernel launch: traj [H, d, R] stays on the GPU."""
+        if traj.shape[2] != len(policies):
+            raise ValueError("one policy per recorded rollout is required")
+        self._device_batches.append((traj, policies))
         self.size += traj.shape[2]
 
-    def materialize(self):
-        """Bring every pending device batch to the reference's host lists."""
-        self._flush()
-        return self
-
     def save(self, path):
-        self._flush()
         np.savez(path, policies=self.policies, trajectories=self.trajectories)
+
+    def load(self, path):
+        with np.load(path, allow_pickle=False) as stored:
+            missing = {"policies", "trajectories"} - set(stored.files)
+            if missing:
+                raise ValueError(f"{path}: not a trajectory store (missing {sorted(missing)})")
+            pols, trajs = stored["policies"], stored["trajectories"]
+        if len(pols) != len(trajs):
+            raise ValueError(f"{path}: {len(pols)} policies for {len(trajs)} trajectories")
+        for trajectory, policy in zip(trajs, pols):
+            self.add_trajectory(trajectory, policy)

@@ -22,7 +22,6 @@ class Estimator(object):
 
     def __init__(self, database, guess_param, capacity, unknowns=('m_i', 'l_i', 'k'),
                  device="cuda:0"):
-        database.materialize() if hasattr(database, "materialize") else None
         assert database.size > 0, "Database is empty"
         assert len(database.trajectories[0]) == guess_param.H, "Rollouts are not the same"
         self.guess_param = guess_param
