@@ -137,6 +137,28 @@ def aux_step_only(sw, n, device):
     return out
 
 
+def aux_more_directions(sw, n, H, device, directions=2048, iters=12):
+    """The same ARS iteration at configs[3]'s problem size (2048 directions = 4096 rollouts) on
+    ONE GPU: the rollout kernel is latency-bound, so the larger batch rides along almost free."""
+    ep = sw.EnvParam("LeonSwimmer-Bench", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("Bench", V1=False, n_iter=iters, H=H, N=directions, b=directions, alpha=0.0075,
+                     nu=0.01, safe=False, threshold=0, initial_w="Zero")
+    state = np.random.get_state()
+    agent = sw.ARSAgent(ep, ap, seed=0, device=device, full_covariance=True)
+    for _ in range(3):
+        agent.run_iteration_async(want_returns=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        agent.run_iteration_async(want_returns=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    np.random.set_state(state)
+    del agent
+    return {"directions": directions, "ms_per_iteration": dt * 1e3,
+            "env_steps_per_s": 2 * directions * H / dt}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,7 +269,8 @@ def main():
         }
         # the step-only sweep and the CPU baseline belong to the N = 1 line only
         if not args.no_aux and world == 1:
-            line["aux"] = {"step_only": aux_step_only(sw, n, device)}
+            line["aux"] = {"step_only": aux_step_only(sw, n, device),
+                           "ars_2048_directions_one_gpu": aux_more_directions(sw, n, H, device)}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, H, args.directions, args.cpu_seconds)
         print(json.dumps(line), flush=True)
