@@ -397,3 +397,28 @@ def test_large_batch_properties(sw):
     out_nt, rew_nt = sw.kernels.step(p, big_s, big_a)
     assert torch.equal(out_nt[:, :B], out) and torch.equal(out_nt[:, -B:], out)
     assert torch.equal(rew_nt[B:2 * B], rew)
+
+
+@pytest.mark.parametrize("n,N", [(3, 512), (6, 256)])
+def test_baseline_size_ars_iterations_vs_oracle(sw, n, N):
+    """BASELINE configs[2] (n = 3, 512 directions x 2 x H = 1000) and the per-GPU shape of
+    configs[4] (n = 6, 256 directions) at FULL size: two ARS V2 iterations on the GPU against
+    the oracle's (1 024 000 resp. 512 000 env-steps per iteration, ~1 s of CPU each)."""
+    from oracle.ars_oracle import ArsOracle
+    H = 1000
+    ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("Test", V1=False, n_iter=2, H=H, N=N, b=N, alpha=0.0075, nu=0.01, safe=False,
+                     threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=0)
+    o = ArsOracle(n, 1.0, 1.0, 10.0, 1e-3, H, N, N, 0.0075, 0.01, False, 0)
+    for it in range(2):
+        r = np.array(agent.runOneIteration())
+        ro = np.array(o.iteration())
+        assert r.shape == (2 * N,)
+        print(f"n={n} N={N} it{it}: max|dR| = {np.abs(r - ro).max():.3e} (|R| up to {np.abs(ro).max():.2f}), "
+              f"max|dP| = {np.abs(agent.policy - o.policy).max():.3e}")
+        assert np.abs(r - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
+        assert np.abs(agent.policy - o.policy).max() <= 1e-10
+        assert np.abs(agent.mean - o.mean).max() <= 1e-10
+        assert cov_close(agent.covariance, o.covariance, 1e-8)
+    assert agent.n_saved_states == 2 * 2 * N * H
