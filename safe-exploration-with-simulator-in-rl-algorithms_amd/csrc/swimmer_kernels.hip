@@ -585,8 +585,8 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             tq0 = __builtin_fma(V[2 + 2 * k], thk[k] - mu[2 + 2 * k], tq0);
             tq1 = __builtin_fma(V[3 + 2 * k], wk[k] - mu[3 + 2 * k], tq1);
         }
-        const double piv = sw::row_step<N>(C, L, gdx, gdy, th, thd, wk, tq0 + tq1);
-        asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(piv));
+        const double rq = sw::row_step<N>(C, L, gdx, gdy, th, thd, wk, tq0 + tq1);
+        asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
         total += __builtin_fma(gdx, C.dirx, gdy * C.diry);
         const double gsel = __builtin_fma(L.gx, gdx, L.gy * gdy);
         if (TRAJ) {
@@ -608,17 +608,19 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
 
     // ---- per-rollout outputs ----
     {
-        double bad[N], big[N];
+        double bad[N], big[N], piv[N];
         const bool fin = isfinite(th) && isfinite(thd) && isfinite(gdx) && isfinite(gdy);
         sw::RowGather<N>::run(fin ? 0.0 : 1.0, bad);
         sw::RowGather<N>::run(thmax, big);
-        double nbad = 0.0, tmax = 0.0;
+        sw::RowGather<N>::run(pivmin_all, piv);   // every segment lane's smallest 1 / pivot
+        double nbad = 0.0, tmax = 0.0, pmin = 1.0;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             nbad += bad[k];
             tmax = fmax(tmax, big[k]);
+            pmin = fmin(pmin, piv[k]);
         }
-        const int code = ((pivmin_all > 0.0) ? 0 : SW_STATUS_SINGULAR) |
+        const int code = ((pmin > 0.0) ? 0 : SW_STATUS_SINGULAR) |
                          ((nbad == 0.0) ? 0 : SW_STATUS_NONFINITE) |
                          ((tmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
         if (valid && q == 0) {

@@ -94,16 +94,13 @@ struct RowGather<N, N> {
     static __device__ __forceinline__ void run(double, double (&)[N]) {}
 };
 
-// Cooperative solve of Q x = b: lane i holds row i (a[0..N-1]) and b_i; returns x_i on lane i.
-// pivmin tracks the smallest pivot (positive definiteness check).
+// Cooperative solve of Q x = b: lane i holds row i (a[0..N-1]) and b_i; ends with x_i on lane i.
+// rq: lane i's 1 / (pivot i) -- its sign doubles as the positive-definiteness check.
 template <int N, int J = 0>
 struct RowEliminate {
-    static __device__ __forceinline__ void run(const RowLane<N> &L, double (&a)[N], double &b,
-                                               double &rq, double &pivmin)
+    static __device__ __forceinline__ void run(const RowLane<N> &L, double (&a)[N], double &b, double &rq)
     {
-        const double pj = row_bcast<J>(a[J]);
-        asm("v_min_f64 %0, %1, %2" : "=v"(pivmin) : "v"(pivmin), "v"(pj));
-        const double rp = rcp_f64(pj);
+        const double rp = rcp_f64(row_bcast<J>(a[J]));
         rq = __builtin_fma(L.one[J], rp, rq);          // lane J keeps 1 / Q_JJ
         if (J < N - 1) {
             const double f = (L.below[J] * a[J]) * rp;  // Q_iJ / Q_JJ on lanes i > J, else 0
@@ -111,36 +108,37 @@ struct RowEliminate {
             for (int k = J + 1; k < N; ++k) a[k] = __builtin_fma(-f, row_bcast<J>(a[k]), a[k]);
             b = __builtin_fma(-f, row_bcast<J>(b), b);
         }
-        RowEliminate<N, J + 1>::run(L, a, b, rq, pivmin);
+        RowEliminate<N, J + 1>::run(L, a, b, rq);
     }
 };
 template <int N>
 struct RowEliminate<N, N> {
-    static __device__ __forceinline__ void run(const RowLane<N> &, double (&)[N], double &, double &,
-                                               double &) {}
+    static __device__ __forceinline__ void run(const RowLane<N> &, double (&)[N], double &, double &) {}
 };
 
+// Back-substitution: step J broadcasts x_J = b_J / Q_JJ (lane J's b is final by then) and the
+// lanes above subtract their U entry times it.  Lane i's b only changes at steps J > i, so
+// after the last step b * rq IS lane i's solution -- no per-step capture needed.
 template <int N, int J = N - 1>
 struct RowBackSub {
-    static __device__ __forceinline__ void run(const RowLane<N> &L, const double (&a)[N], double &b,
-                                               double rq, double &x)
+    static __device__ __forceinline__ void run(const RowLane<N> &L, const double (&a)[N], double &b, double rq)
     {
-        const double xj = row_bcast<J>(b * rq);        // lane J's b is final here
-        x = __builtin_fma(L.one[J], xj, x);
-        if (J > 0) b = __builtin_fma(-(L.above[J] * a[J]), xj, b);
-        RowBackSub<N, J - 1>::run(L, a, b, rq, x);
+        if (J > 0) {
+            const double xj = row_bcast<J>(b * rq);
+            b = __builtin_fma(-(L.above[J] * a[J]), xj, b);
+        }
+        RowBackSub<N, J - 1>::run(L, a, b, rq);
     }
 };
 template <int N>
 struct RowBackSub<N, -1> {
-    static __device__ __forceinline__ void run(const RowLane<N> &, const double (&)[N], double &,
-                                               double, double &) {}
+    static __device__ __forceinline__ void run(const RowLane<N> &, const double (&)[N], double &, double) {}
 };
 
 // One explicit-Euler step.  gdx, gdy: replicated (bit-identical on all lanes); th, thd: own
 // segment; wk: every segment's thetadot (already gathered by the caller for the policy);
-// tq_scaled = c12 (u_{i-1} - u_i) for this lane's segment.  Returns the smallest pivot of
-// the elimination.
+// tq_scaled = c12 (u_{i-1} - u_i) for this lane's segment.  Returns this lane's reciprocal
+// pivot (positive for a positive definite system).
 template <int N>
 __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L, double &gdx,
                                            double &gdy, double &th, double &thd,
@@ -184,14 +182,15 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
     double a[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) a[k] = __builtin_fma(L.t6[k], cc[k], L.one[k] * L.qd);
-    double rq = 0.0, pivmin = 1.0, tdd = 0.0;
-    RowEliminate<N>::run(L, a, r, rq, pivmin);
-    RowBackSub<N>::run(L, a, r, rq, tdd);
+    double rq = 0.0;
+    RowEliminate<N>::run(L, a, r, rq);
+    RowBackSub<N>::run(L, a, r, rq);
+    const double tdd = r * rq;
     gdx = __builtin_fma(C.h, gddx, gdx);
     gdy = __builtin_fma(C.h, gddy, gdy);
     th = __builtin_fma(C.h, thd, th);
     thd = __builtin_fma(C.h, tdd, thd);
-    return pivmin;
+    return rq;
 }
 
 }  // namespace sw
