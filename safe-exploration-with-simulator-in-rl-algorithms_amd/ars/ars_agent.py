@@ -108,8 +108,9 @@ class ARSAgent(object):
         width = 2 * self.d
         self._seg_len = segment_len(self.chunk, self.rows_chunk, width)
         self._send = torch.zeros(self._seg_len, **f64)
+        from . import sharding as _sh
         self._gathered = (torch.zeros(self.world * self._seg_len, **f64)
-                          if self.world > 1 else self._send)
+                          if (self.world > 1 or _sh._FORCE_COLLECTIVE) else self._send)
         self._returns_local = self._send[:2 * self.n_local]
         rows_local = kernels.moments_blocks(2 * self.n_local) if self.v2 else 0
         self._moments_local = (self._send[2 * self.chunk:2 * self.chunk + rows_local * width]

@@ -62,6 +62,12 @@ def exchange(returns_local, moments_local, n_dir, world, group=None, rows_chunk=
     return returns_all, moments_all
 
 
+# experiment knob: issue the collective even for a single rank (measures the framework +
+# RCCL launch overhead an iteration pays when world > 1, on a one-GPU box)
+import os as _os
+_FORCE_COLLECTIVE = bool(_os.environ.get("SWIMMER_FORCE_COLLECTIVE"))
+
+
 def segment_len(chunk, rows_chunk, width):
     """Doubles in one rank's packed segment [2*chunk returns | rows_chunk x width moments]."""
     return 2 * chunk + rows_chunk * width
@@ -71,7 +77,7 @@ def all_gather_segments(send, gathered, world, group=None):
     """gathered[r*L:(r+1)*L] <- rank r's `send` (L doubles).  One collective, no repacking:
     the rollout kernel writes returns and moment rows straight into `send`, and the update
     kernel indexes `gathered` in place (sw_ars_update_gathered_f64)."""
-    if world == 1:
+    if world == 1 and not _FORCE_COLLECTIVE:
         return send
     if send.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no GPU all-gather: stage through the host (tests / debugging only)
