@@ -422,3 +422,37 @@ def test_baseline_size_ars_iterations_vs_oracle(sw, n, N):
         assert np.abs(agent.mean - o.mean).max() <= 1e-10
         assert cov_close(agent.covariance, o.covariance, 1e-8)
     assert agent.n_saved_states == 2 * 2 * N * H
+
+
+@pytest.mark.parametrize("n", [3, 6])
+def test_physical_invariants_at_scale(sw, n):
+    """Size-independent properties of the model on 2^20 swimmers (no oracle needed):
+    the barycentre acceleration ignores the joint torques (internal forces), and rotating the
+    whole swimmer (angles, barycentre velocity) rotates Gdd and leaves thdd unchanged."""
+    dev = "cuda:0"
+    B = 1 << 20
+    g = torch.Generator(device=dev).manual_seed(3)
+    d, m = 2 * n + 2, n - 1
+    st = torch.empty((d, B), dtype=torch.float64, device=dev)
+    st[0:2] = torch.rand((2, B), generator=g, device=dev, dtype=torch.float64) - 0.5
+    st[2::2] = (torch.rand((n, B), generator=g, device=dev, dtype=torch.float64) - 0.5) * 2 * np.pi
+    st[3::2] = (torch.rand((n, B), generator=g, device=dev, dtype=torch.float64) - 0.5) * 4
+    u1 = (torch.rand((m, B), generator=g, device=dev, dtype=torch.float64) - 0.5) * 10
+    u2 = (torch.rand((m, B), generator=g, device=dev, dtype=torch.float64) - 0.5) * 10
+    p = sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3)
+    gdd1, tdd1 = sw.kernels.accelerations(p, st, u1)
+    gdd2, tdd2 = sw.kernels.accelerations(p, st, u2)
+    assert torch.equal(gdd1, gdd2)                       # Gdd decouples from the torques
+    assert float((tdd1 - tdd2).abs().max()) > 1.0       # ... while thdd does not
+    phi = 0.7321
+    c, s_ = np.cos(phi), np.sin(phi)
+    rot = st.clone()
+    rot[0] = c * st[0] - s_ * st[1]
+    rot[1] = s_ * st[0] + c * st[1]
+    rot[2::2] = st[2::2] + phi
+    gdd_r, tdd_r = sw.kernels.accelerations(p, rot, u1)
+    scale = float(tdd1.abs().max())
+    assert float((tdd_r - tdd1).abs().max()) <= 1e-11 * scale
+    gx = c * gdd1[0] - s_ * gdd1[1]
+    gy = s_ * gdd1[0] + c * gdd1[1]
+    assert float(torch.maximum((gdd_r[0] - gx).abs(), (gdd_r[1] - gy).abs()).max()) <= 1e-12 * max(1.0, float(gdd1.abs().max()))
