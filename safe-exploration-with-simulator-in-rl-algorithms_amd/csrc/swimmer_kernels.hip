@@ -377,8 +377,12 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
     const sw::Quad3Lane L = sw::quad3_lane(seg);
     const int cth = 2 + 2 * seg, cthd = 3 + 2 * seg;
 
-    // ---- this lane's four policy columns: Gdot (segment 0 only), theta_i, thetadot_i ----
-    double Wg0[M], Wg1[M], Wth[M], Wthd[M];
+    // ---- this lane's policy row: V_i = c12 (W_{i-1} - W_i), W = (P +- nu delta) diag(inv_std)
+    // (ars_agent.py:141-142, environment.py:32-34), u_{-1} = u_2 = 0 (free ends); columns in
+    // this lane's rotated order [Gdx, Gdy, th_i, thd_i, th_i1, thd_i1, th_i2, thd_i2]
+    const int seg1 = (seg + 1) % 3, seg2 = (seg + 2) % 3;
+    const int cols[D] = {0, 1, cth, cthd, 2 + 2 * seg1, 3 + 2 * seg1, 2 + 2 * seg2, 3 + 2 * seg2};
+    double V[D], mu[D];
     {
         const double *pl = ARS ? policies : policies + r * (M * D);
         const double *dl = ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr;
@@ -390,15 +394,13 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
             return w;
         };
 #pragma unroll
-        for (int a = 0; a < M; ++a) {
-            Wg0[a] = (seg == 0) ? entry(a, 0) : 0.0;
-            Wg1[a] = (seg == 0) ? entry(a, 1) : 0.0;
-            Wth[a] = entry(a, cth);
-            Wthd[a] = entry(a, cthd);
+        for (int j = 0; j < D; ++j) {
+            const double up = (seg >= 1) ? entry(seg - 1, cols[j]) : 0.0;
+            const double dn = (seg <= M - 1) ? entry(seg, cols[j]) : 0.0;
+            V[j] = C.c12 * (up - dn);
+            mu[j] = mean ? mean[cols[j]] : 0.0;
         }
     }
-    const double mu0 = mean ? mean[0] : 0.0, mu1 = mean ? mean[1] : 0.0;
-    const double muth = mean ? mean[cth] : 0.0, muthd = mean ? mean[cthd] : 0.0;
 
     // ---- start state ----
     double gdx = 0.0, gdy = 0.0, th = kHalfPi, thd = 0.0;
@@ -429,17 +431,24 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
 
     double total = 0.0, thmax = 0.0, detmin = 1.0;
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
+    // neighbours' angle / angular velocity for the next step's policy: exchanged at the END of a
+    // step (behind the stores and moment updates), so the DPP reads never wait on the Euler
+    // update that just wrote them
+    double t1 = sw::dpp_f64<sw::kDppNext1>(th), t2 = sw::dpp_f64<sw::kDppNext2>(th);
+    double w1 = sw::dpp_f64<sw::kDppNext1>(thd), w2 = sw::dpp_f64<sw::kDppNext2>(thd);
     for (int32_t t = 0; t < H; ++t) {
         asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
-        // partial action of this lane's columns, then the sum over the three segments
-        const double e0 = gdx - mu0, e1 = gdy - mu1, e2 = th - muth, e3 = thd - muthd;
-        double p0 = __builtin_fma(Wthd[0], e3, __builtin_fma(Wth[0], e2,
-                    __builtin_fma(Wg1[0], e1, Wg0[0] * e0)));
-        double p1 = __builtin_fma(Wthd[1], e3, __builtin_fma(Wth[1], e2,
-                    __builtin_fma(Wg1[1], e1, Wg0[1] * e0)));
-        const double u0 = (p0 + sw::dpp_f64<sw::kDppNext1>(p0)) + sw::dpp_f64<sw::kDppNext2>(p0);
-        const double u1 = (p1 + sw::dpp_f64<sw::kDppNext1>(p1)) + sw::dpp_f64<sw::kDppNext2>(p1);
-        const double det = sw::quad3_step(C, L, gdx, gdy, th, thd, u0, u1);
+        // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean); the
+        // neighbours' angles and angular velocities arrive by DPP (the velocities are reused
+        // by the physics step)
+        double tqa = V[0] * (gdx - mu[0]), tqb = V[1] * (gdy - mu[1]);
+        tqa = __builtin_fma(V[2], th - mu[2], tqa);
+        tqb = __builtin_fma(V[3], thd - mu[3], tqb);
+        tqa = __builtin_fma(V[4], t1 - mu[4], tqa);
+        tqb = __builtin_fma(V[5], w1 - mu[5], tqb);
+        tqa = __builtin_fma(V[6], t2 - mu[6], tqa);
+        tqb = __builtin_fma(V[7], w2 - mu[7], tqb);
+        const double det = sw::quad3_step(C, L, gdx, gdy, th, thd, w1, w2, tqa + tqb);
         asm("v_min_f64 %0, %1, %2" : "=v"(detmin) : "v"(detmin), "v"(det));
         total += __builtin_fma(gdx, C.dirx, gdy * C.diry);
         const double gsel = __builtin_fma(L.gx, gdx, L.gy * gdy);
@@ -458,6 +467,10 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
             m1g += gsel;
             m2g = __builtin_fma(gsel, gsel, m2g);
         }
+        t1 = sw::dpp_f64<sw::kDppNext1>(th);
+        t2 = sw::dpp_f64<sw::kDppNext2>(th);
+        w1 = sw::dpp_f64<sw::kDppNext1>(thd);
+        w2 = sw::dpp_f64<sw::kDppNext2>(thd);
     }
 
     // ---- per-rollout outputs (quad lanes 0..2 hold the state; lane 0 the return) ----

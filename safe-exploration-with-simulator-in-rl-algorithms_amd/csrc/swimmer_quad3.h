@@ -9,8 +9,10 @@
 // instructions per step at 4x the (idle anyway) SIMD count:
 //
 //   lane q = 0,1,2 of a quad owns segment q: its angle, angular velocity, sin/cos, its row
-//   of the 3x3 joint-acceleration system, its two columns of the linear policy and its V2
-//   moment sums; lane 3 mirrors lane 0 bit for bit (same inputs, same permutation sources),
+//   of the 3x3 joint-acceleration system and its V2 moment sums.  The joint torques are never
+//   formed: lane i only needs u_{i-1} - u_i, which is linear in the observation, so it holds
+//   the pre-combined policy row V_i = 12/(m l^2) (W_{i-1} - W_i) (columns in its rotated
+//   order) and evaluates one 8-term dot product on (observation - mean); lane 3 mirrors lane 0 bit for bit (same inputs, same permutation sources),
 //   so whatever it stores duplicates lane 0's stores.
 //   Neighbour data moves with DPP quad_perm moves (no LDS, no memory, two 32-bit moves per
 //   double): next1 = segment (q+1)%3, next2 = segment (q+2)%3.
@@ -52,7 +54,6 @@ struct Quad3Lane {
     double a0, a1, a2;      // Aw(i,i), Aw(i,i1), Aw(i,i2)
     double t1, t2, t12;     // -6 T(i,i1), -6 T(i,i2), -6 T(i1,i2)
     double d0, d12, d1, d2; // diagonal of Q in rotated order, d12 = d1*d2
-    double ta, tb;          // joint-torque balance u_{i-1} - u_i = ta*u0 + tb*u1
     double gx, gy;          // Gdot component this lane records: x on segment 0, y on 1 and 2
 };
 
@@ -76,26 +77,24 @@ __device__ __forceinline__ Quad3Lane quad3_lane(int seg)
     L.d1 = pick(D2, D3, D1);
     L.d2 = pick(D3, D1, D2);
     L.d12 = L.d1 * L.d2;
-    L.ta = pick(-1.0, 1.0, 0.0);
-    L.tb = pick(0.0, -1.0, 1.0);
     L.gx = pick(1.0, 0.0, 0.0);
     L.gy = pick(0.0, 1.0, 1.0);
     return L;
 }
 
 // One explicit-Euler step of one rollout spread over a quad.  On entry/exit: gdx, gdy
-// replicated, th/thd own segment.  u0, u1: joint torques (identical on all lanes up to
-// summation order).  Returns det of the (rotated) system for the singularity check.
+// replicated, th/thd own segment.  w1, w2: the neighbours' angular velocities (the caller
+// exchanged them for the policy already); tq_scaled = 12/(m l^2) (u_{i-1} - u_i), this
+// segment's joint-torque balance.  Returns det of the (rotated) system for the singularity check.
 __device__ __forceinline__ double quad3_step(const Consts &C, const Quad3Lane &L, double &gdx,
-                                             double &gdy, double &th, double &thd, double u0,
-                                             double u1)
+                                             double &gdy, double &th, double &thd, double w1,
+                                             double w2, double tq_scaled)
 {
     double s, c;
     sincos_fast(th, s, c);
-    // neighbours' sin, cos, angular velocity
+    // neighbours' sin, cos
     const double s1 = dpp_f64<kDppNext1>(s), c1 = dpp_f64<kDppNext1>(c);
     const double s2 = dpp_f64<kDppNext2>(s), c2 = dpp_f64<kDppNext2>(c);
-    const double w1 = dpp_f64<kDppNext1>(thd), w2 = dpp_f64<kDppNext2>(thd);
     // cos(th_i - th_k), sin(th_k - th_i)
     const double cc1 = __builtin_fma(c, c1, s * s1), cc2 = __builtin_fma(c, c2, s * s2);
     const double cc12 = __builtin_fma(c1, c2, s1 * s2);
@@ -116,10 +115,9 @@ __device__ __forceinline__ double quad3_step(const Consts &C, const Quad3Lane &L
     double fric = L.a0 * g;
     fric = __builtin_fma(L.a1 * cc1, g1, fric);
     fric = __builtin_fma(L.a2 * cc2, g2, fric);
-    const double tq = __builtin_fma(L.ta, u0, L.tb * u1);
     double r0 = __builtin_fma(-C.six_k_m, fric, cent);
     r0 = __builtin_fma(C.kl_m, thd, r0);
-    r0 = __builtin_fma(C.c12, tq, r0);
+    r0 += tq_scaled;
     const double r1 = dpp_f64<kDppNext1>(r0), r2 = dpp_f64<kDppNext2>(r0);
     // first row of the adjugate of [[d0,a,b],[a,d1,e],[b,e,d2]]
     const double a = L.t1 * cc1, b = L.t2 * cc2, e = L.t12 * cc12;
