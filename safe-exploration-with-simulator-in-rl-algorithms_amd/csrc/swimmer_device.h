@@ -131,15 +131,16 @@ __device__ __forceinline__ double track_angle_range(double acc, const double (&t
     return acc;
 }
 
-// 1/x for a well-scaled positive x: hardware estimate + two Newton steps (full fp64).
+// 1/x for a well-scaled x: hardware estimate + two Newton steps (full fp64).  The second step
+// reuses the squared residual (r1 = r0 (1 + e) has residual e^2) instead of recomputing it from
+// x: same five instructions, one level less on the dependency chain that ends every step.
 __device__ __forceinline__ double rcp_f64(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e, r0);
+    const double e2 = e * e;
+    return __builtin_fma(r1, e2, r1);
 }
 
 // ---- symmetric positive definite solve ---------------------------------------------
