@@ -586,12 +586,14 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
 
     double total = 0.0, thmax = 0.0, pivmin_all = 1.0;
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
+    double thk[N], wk[N];
+    sw::RowGather<N>::run(th, thk);
+    sw::RowGather<N>::run(thd, wk);
     for (int32_t t = 0; t < H; ++t) {
         asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
-        // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean)
-        double thk[N], wk[N];
-        sw::RowGather<N>::run(th, thk);
-        sw::RowGather<N>::run(thd, wk);
+        // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean); thk / wk
+        // (every segment's angle / angular velocity) were gathered at the end of the previous
+        // step, behind its stores and moment updates
         double tq0 = V[0] * (gdx - mu[0]), tq1 = V[1] * (gdy - mu[1]);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
@@ -617,6 +619,8 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             m1g += gsel;
             m2g = __builtin_fma(gsel, gsel, m2g);
         }
+        sw::RowGather<N>::run(th, thk);
+        sw::RowGather<N>::run(thd, wk);
     }
 
     // ---- per-rollout outputs ----
