@@ -1,19 +1,24 @@
 // swimmer_kernels.hip -- gfx950 kernels + the C ABI of include/swimmer_hip.h.
 //
-// Kernels (all fp64, one swimmer / rollout per lane, no MFMA: the largest contraction on
-// this path is 8x8):
-//   step_kernel<N>      one physics step, SoA in / SoA out; HBM-bound at large n_env
-//                       (algorithmic traffic 16 (2n+2) + 8 (n-1) + 8 bytes per env-step).
-//                       One env per lane on purpose: a two-envs-per-lane variant with 16-byte
-//                       accesses measured SLOWER at >= 4M envs (4.87 vs 5.62 TB/s: 90 VGPRs,
-//                       5 waves/SIMD, fewer loads in flight per CU) and was dropped.
-//   accel_kernel<N>     accelerations only
-//   rollout_kernel<N,ARS>  H steps with the state, the whitened policy, the return and the
-//                       V2 moment sums held in registers; optional coalesced trajectory
-//                       stores (8 (2n+2) bytes per env-step); fp64-VALU-issue bound
-//   ars_update_kernel   sigma_R, policy update, V2 statistics merge (one workgroup per
-//                       policy entry + one for the statistics)
-//   traj_moments_kernel full first/second moments of a trajectory buffer; HBM-bound
+// All arithmetic is fp64 on the vector ALUs; there is no MFMA (the largest contraction on this
+// path is 8x8) and no LDS in the hot loops (neighbour data moves by DPP).
+//
+//   step_kernel<N,TWIN,NT>     one physics step, SoA in / SoA out, one env per lane; HBM-bound
+//                              at large n_env (algorithmic traffic 16 (2n+2) + 8 (n-1) + 8 bytes
+//                              per env-step); NT = nontemporal accesses for streaming batches.
+//                              A two-envs-per-lane variant with 16-byte accesses measured SLOWER
+//                              (4.87 vs 5.62 TB/s: 90 VGPRs, fewer loads in flight) and was dropped.
+//   accel_kernel<N,TWIN>       accelerations only
+//   rollout_quad3_kernel       n = 3, H steps in one launch, ONE SEGMENT PER LANE (DPP quad per
+//                              rollout, swimmer_quad3.h): the latency form, instruction-issue bound
+//   rollout_row_kernel<N>      n = 4..8, one segment per lane, one rollout per 16-lane DPP row
+//                              (swimmer_row.h)
+//   rollout_kernel<N,ARS,TWIN> any n, ONE ROLLOUT PER LANE: the throughput form for batches that
+//                              fill the chip, and the only form of the twin model
+//   ars_update_kernel          sigma_R, policy step, V2 statistics merge; pure latency between
+//                              two rollout launches: one round of loads, then LDS only
+//   traj_moments_kernel<D>     full first/second moments of a trajectory buffer; HBM-bound
+//   + the native ARS iteration pipeline (sw_ars_pipeline_*: three streams, 4-slot buffer ring)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
