@@ -63,7 +63,7 @@ def parse():
 def pmc_traffic(kernel, n, directions, H):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None when
     the measured workload is not the one being benchmarked."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
     if not os.path.exists(path) or (n, directions, H) != (3, 512, 1000):
         return None
     return json.load(open(path)).get(kernel, {}).get("traffic_bytes")
