@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MEASURED_COPY_PEAK_GBPS = 5690.0   # scripts/ubench/stream_copy on the box (profiles/r01_g_stream_copy.log)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 # Instructions one wave issues per env-step in the segment-per-lane rollout kernels (ISA count
 # of the hot loop incl. trajectory stores + moments, scripts/isa_loop_stats.py) and the measured
@@ -133,7 +134,8 @@ def aux_step_only(sw, n, device):
         byts = (2 * d + m + 1) * 8 * B
         out[tag] = {"us_per_launch": per * 1e6, "env_steps_per_s": B / per,
                     "algorithmic_GBps": byts / per / 1e9,
-                    "hbm_frac": byts / per / 1e9 / HBM_PEAK_GBPS}
+                    "hbm_frac": byts / per / 1e9 / HBM_PEAK_GBPS,
+                    "frac_of_measured_copy_peak": byts / per / 1e9 / MEASURED_COPY_PEAK_GBPS}
     return out
 
 

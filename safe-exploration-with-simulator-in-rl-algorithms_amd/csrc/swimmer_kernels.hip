@@ -1094,7 +1094,9 @@ int sw_step_f64(const sw_params *p, int64_t n_env, const double *state_in, const
     const unsigned grid = (unsigned)((n_env + kStepBlock - 1) / kStepBlock);
     const sw::TwinConsts T = make_twin_consts(p);
     const int d = 2 * p->n + 2;
-    const bool nt = n_env * (int64_t)(8 * (2 * d + p->n)) > kStepStreamBytes;
+    bool nt = n_env * (int64_t)(8 * (2 * d + p->n)) > kStepStreamBytes;
+    static const char *nt_env = getenv("SWIMMER_STEP_NT");   // measurement knob: "0" / "1" force it
+    if (nt_env && (nt_env[0] == '0' || nt_env[0] == '1')) nt = nt_env[0] == '1';
     if (is_twin(p)) {
         SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_kernel<NN, true, false>), dim3(grid), dim3(kStepBlock), 0,
                                                (hipStream_t)stream, C, T, n_env, state_in, action,

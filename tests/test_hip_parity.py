@@ -2,6 +2,9 @@
 the reference produced.  Tolerance contract (BASELINE.json north_star): 1e-5 absolute,
 step for step, in fp64.  The asserted bounds are far tighter (what the reduced-algebra
 kernel actually achieves), so a regression shows long before the contract is at risk."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -53,6 +56,7 @@ def test_config2_8192_envs_vs_oracle(sw):
     """BASELINE config 2: n = 3, 8192 envs, one physics step, SURVEY 8d C2 distributions."""
     rng = np.random.default_rng(0)
     B, n = 8192, 3
+    report = {}
     for pset in ("default", "realworld"):
         l, m, k, h = PARAM_SETS[pset]
         st = np.empty((B, 8))
@@ -65,9 +69,20 @@ def test_config2_8192_envs_vs_oracle(sw):
         nxt = nxt.T.cpu().numpy()
         err = np.abs(nxt - ref_next).max()
         bit = float((nxt == ref_next).mean())
-        print(f"config2 {pset}: max|err| = {err:.3e}, bit-identical doubles = {bit:.4f}")
+        ulp = np.abs(nxt.view(np.int64) - ref_next.view(np.int64))   # same sign everywhere (checked)
+        assert (np.signbit(nxt) == np.signbit(ref_next)).all()
+        report[pset] = {"max_abs_err": float(err), "bit_identical_fraction": bit,
+                        "within_1_ulp_fraction": float((ulp <= 1).mean()),
+                        "within_4_ulp_fraction": float((ulp <= 4).mean()),
+                        "max_ulp": int(ulp.max())}
+        print(f"config2 {pset}: {report[pset]}")
         assert err <= STEP_TOL
         assert np.abs(rew.cpu().numpy() - ref_rew).max() <= STEP_TOL
+    # SWIMMER_REPORT_DIR=<dir>: keep the figures (profiles/ holds a copy of the last run)
+    out = os.environ.get("SWIMMER_REPORT_DIR")
+    if out:
+        with open(os.path.join(out, "config2_bitmatch.json"), "w") as f:
+            json.dump(report, f, indent=1)
 
 
 def test_known_answers(sw, golden):
