@@ -44,6 +44,7 @@ struct Consts {
     double h;        // Euler step
     double dirx, diry;
     double kl_nm;    // k l / (n m)
+    double h_kl_nm;  // h k l / (n m): barycentre Euler update in one FMA (segment-per-lane kernels)
     double six_k_m;  // 6 k / m
     double kl_m;     // k l / m
     double c12;      // 12 / (m l^2)
@@ -67,9 +68,10 @@ template <int N> __host__ __device__ constexpr double Aw(int i1, int j1)
 }
 
 // ---- sin and cos ----------------------------------------------------------------------
-// Cody-Waite reduction by pi/2 with three FMAs (pi/2 = H + M + L split into doubles; the
-// first FMA is exact, the other two round once each relative to the *reduced* argument, so
-// the result keeps ~1 ulp even next to multiples of pi/2) + the classic degree-13 /
+// Cody-Waite reduction by pi/2 with two FMAs (pi/2 = H + M + ..., H = fl(pi/2); the first FMA
+// is exact, the second rounds once relative to the *reduced* argument; the next term of the
+// split is 1.5e-33 and would move the result by < 1.5e-24 |k| <= 5e-15 ulp(1) inside the valid
+// range, so it is not spent) + the classic degree-13 /
 // degree-14 minimax kernels on [-pi/4, pi/4] (coefficients: Sun fdlibm k_sin.c / k_cos.c,
 // public domain).  Valid for |x| < kAngleLimit (quadrant index must fit 31 bits); callers
 // flag larger / non-finite angles with SW_STATUS_RANGE instead of computing garbage.
@@ -88,6 +90,16 @@ __device__ __forceinline__ double fma3(double a, double b, double c)
     return d;
 }
 
+// a * b + coef with the coefficient read straight from a scalar register pair (one constant-bus
+// operand per VALU instruction on gfx9): the polynomial coefficients never occupy VGPRs and the
+// compiler has no reason to re-materialise them with v_mov inside an unrolled loop
+__device__ __forceinline__ double fma3_sc(double a, double b, double coef)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(coef));
+    return d;
+}
+
 __device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_out)
 {
     const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: integer part lands in the low bits
@@ -96,18 +108,17 @@ __device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_o
     const uint32_t q = (uint32_t)__double_as_longlong(kd_m);
     double r = __builtin_fma(-kd, 1.5707963267948966, x);       // exact
     r = __builtin_fma(-kd, 6.123233995736766e-17, r);
-    r = __builtin_fma(-kd, -1.4973849048591698e-33, r);
     const double z = r * r;
-    double ps = fma3(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
-    ps = fma3(ps, z, 2.75573137070700676789e-06);
-    ps = fma3(ps, z, -1.98412698298579493134e-04);
-    ps = fma3(ps, z, 8.33333333332248946124e-03);
-    ps = fma3(ps, z, -1.66666666666666324348e-01);
-    double pc = fma3(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
-    pc = fma3(pc, z, -2.75573143513906633035e-07);
-    pc = fma3(pc, z, 2.48015872894767294178e-05);
-    pc = fma3(pc, z, -1.38888888888741095749e-03);
-    pc = fma3(pc, z, 4.16666666666666019037e-02);
+    double ps = fma3_sc(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+    ps = fma3_sc(ps, z, 2.75573137070700676789e-06);
+    ps = fma3_sc(ps, z, -1.98412698298579493134e-04);
+    ps = fma3_sc(ps, z, 8.33333333332248946124e-03);
+    ps = fma3_sc(ps, z, -1.66666666666666324348e-01);
+    double pc = fma3_sc(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+    pc = fma3_sc(pc, z, -2.75573143513906633035e-07);
+    pc = fma3_sc(pc, z, 2.48015872894767294178e-05);
+    pc = fma3_sc(pc, z, -1.38888888888741095749e-03);
+    pc = fma3_sc(pc, z, 4.16666666666666019037e-02);
     const double sr = __builtin_fma(r * z, ps, r);
     const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
     // quadrant: bit0 of q swaps sin/cos, bit1 negates sin, bit1 ^ bit0 (= (q+1)&2) negates cos
@@ -141,6 +152,18 @@ __device__ __forceinline__ double rcp_f64(double x)
     const double r1 = __builtin_fma(r0, e, r0);
     const double e2 = e * e;
     return __builtin_fma(r1, e2, r1);
+}
+
+// 1/x from the hardware estimate + ONE Newton step: relative error <= 2.2e-15 (measured over
+// 2^20 arguments, scripts/ubench/store_rcp.hip; the raw estimate is good to 4.6e-8).  Used where
+// the reciprocal sits on the serial pivot chain of a segment-per-lane solve and 20 ulp in
+// thetaddot (h * 2e-15 * |thetaddot| ~ 1e-17 in thetadot per step) is far inside the rounding
+// noise of the step.
+__device__ __forceinline__ double rcp_f64_1n(double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r0, 1.0);
+    return __builtin_fma(r0, e, r0);
 }
 
 // ---- symmetric positive definite solve ---------------------------------------------

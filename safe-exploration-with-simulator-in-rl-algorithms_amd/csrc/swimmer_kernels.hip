@@ -62,6 +62,7 @@ sw::Consts make_consts(const sw_params *p)
     c.dirx = p->dir_x;
     c.diry = p->dir_y;
     c.kl_nm = p->k * p->l_i / ((double)p->n * p->m_i);
+    c.h_kl_nm = c.h * c.kl_nm;
     c.six_k_m = 6.0 * p->k / p->m_i;
     c.kl_m = p->k * p->l_i / p->m_i;
     c.c12 = 12.0 / (p->m_i * p->l_i * p->l_i);
@@ -215,9 +216,7 @@ rollout_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_roll, int32_t H, const 
 
     if (active) {
         // ---- policy into registers ----
-        double W[M][D], mu[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) mu[j] = v2 ? mean[j] : 0.0;
+        double W[M][D];
         if (ARS) {
             const int64_t dir = dir_begin + (r >> 1);
             const double sgn = (r & 1) ? -1.0 : 1.0;
@@ -242,6 +241,16 @@ rollout_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_roll, int32_t H, const 
                 const double sc = inv_std[j];
 #pragma unroll
                 for (int i = 0; i < M; ++i) W[i][j] = __dmul_rn(W[i][j], sc);
+            }
+        }
+        // action = W (s - mu) = W s - W mu: the constant part once per rollout
+        double nbias[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            nbias[i] = 0.0;
+            if (v2) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) nbias[i] = __builtin_fma(-W[i][j], mean[j], nbias[i]);
             }
         }
 
@@ -271,17 +280,17 @@ rollout_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_roll, int32_t H, const 
             thmax = sw::track_angle_range<N>(thmax, th);
             // action = W (s - mu)   (ars/environment.py:29 / :34); two partial sums
             double sm[D];
-            sm[0] = gdx - mu[0];
-            sm[1] = gdy - mu[1];
+            sm[0] = gdx;
+            sm[1] = gdy;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                sm[2 + 2 * i] = th[i] - mu[2 + 2 * i];
-                sm[3 + 2 * i] = thd[i] - mu[3 + 2 * i];
+                sm[2 + 2 * i] = th[i];
+                sm[3 + 2 * i] = thd[i];
             }
             double u[M];
 #pragma unroll
             for (int i = 0; i < M; ++i) {
-                double a0 = W[i][0] * sm[0], a1 = W[i][1] * sm[1];
+                double a0 = __builtin_fma(W[i][0], sm[0], nbias[i]), a1 = W[i][1] * sm[1];
 #pragma unroll
                 for (int j = 2; j < D; j += 2) {
                     a0 = __builtin_fma(W[i][j], sm[j], a0);
@@ -387,7 +396,7 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
     // this lane's rotated order [Gdx, Gdy, th_i, thd_i, th_i1, thd_i1, th_i2, thd_i2]
     const int seg1 = (seg + 1) % 3, seg2 = (seg + 2) % 3;
     const int cols[D] = {0, 1, cth, cthd, 2 + 2 * seg1, 3 + 2 * seg1, 2 + 2 * seg2, 3 + 2 * seg2};
-    double V[D], mu[D];
+    double V[D], nbias = 0.0;   // nbias = -V . mean: tq = V . (obs - mean) without per-step subtractions
     {
         const double *pl = ARS ? policies : policies + r * (M * D);
         const double *dl = ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr;
@@ -403,7 +412,7 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
             const double up = (seg >= 1) ? entry(seg - 1, cols[j]) : 0.0;
             const double dn = (seg <= M - 1) ? entry(seg, cols[j]) : 0.0;
             V[j] = C.c12 * (up - dn);
-            mu[j] = mean ? mean[cols[j]] : 0.0;
+            if (mean) nbias = __builtin_fma(-V[j], mean[cols[j]], nbias);
         }
     }
 
@@ -422,7 +431,11 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
     // by the hardware range check, never written elsewhere).
     const uint32_t off_th = (uint32_t)(((int64_t)cth * n_roll + r) * 8);
     const uint32_t off_thd = (uint32_t)(((int64_t)cthd * n_roll + r) * 8);
+    // Gdot is replicated on every lane: segment 0's lanes record (store and sum) x, the others
+    // y.  ONE store of a per-lane selected value: a store costs ~16 issue cycles (measured), the
+    // select 2 x 4.4
     const uint32_t off_g = (uint32_t)(((int64_t)(seg == 0 ? 0 : 1) * n_roll + r) * 8);
+    const double selx = (seg == 0) ? 1.0 : 0.0, sely = 1.0 - selx;
     const uint32_t slab = (uint32_t)(D * n_roll * 8);
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
         traj, 0, TRAJ ? (int)(uint32_t)((int64_t)H * slab) : 0, 0x00020000);
@@ -434,29 +447,39 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
     };
 
-    double total = 0.0, thmax = 0.0, detmin = 1.0;
-    double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
+    double thmax = 0.0, detmin = 1.0;
+    double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
+    double m1g = 0.0, m2g = 0.0;   // sums of this lane's Gdot component and its square
     // neighbours' angle / angular velocity for the next step's policy: exchanged at the END of a
     // step (behind the stores and moment updates), so the DPP reads never wait on the Euler
     // update that just wrote them
     double t1 = sw::dpp_f64<sw::kDppNext1>(th), t2 = sw::dpp_f64<sw::kDppNext2>(th);
     double w1 = sw::dpp_f64<sw::kDppNext1>(thd), w2 = sw::dpp_f64<sw::kDppNext2>(thd);
-    for (int32_t t = 0; t < H; ++t) {
+    sw::Quad3Geo G = sw::quad3_geometry(th), Gn;
+    // one step: consumes the geometry Gc of theta_t, produces Gx for theta_{t+1}
+    auto one_step = [&](const sw::Quad3Geo &Gc, sw::Quad3Geo &Gx) {
         asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
         // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean); the
         // neighbours' angles and angular velocities arrive by DPP (the velocities are reused
         // by the physics step)
-        double tqa = V[0] * (gdx - mu[0]), tqb = V[1] * (gdy - mu[1]);
-        tqa = __builtin_fma(V[2], th - mu[2], tqa);
-        tqb = __builtin_fma(V[3], thd - mu[3], tqb);
-        tqa = __builtin_fma(V[4], t1 - mu[4], tqa);
-        tqb = __builtin_fma(V[5], w1 - mu[5], tqb);
-        tqa = __builtin_fma(V[6], t2 - mu[6], tqa);
-        tqb = __builtin_fma(V[7], w2 - mu[7], tqb);
-        const double det = sw::quad3_step(C, L, gdx, gdy, th, thd, w1, w2, tqa + tqb);
+        double tqa = __builtin_fma(V[0], gdx, nbias), tqb = V[1] * gdy;
+        tqa = __builtin_fma(V[2], th, tqa);
+        tqb = __builtin_fma(V[3], thd, tqb);
+        tqa = __builtin_fma(V[4], t1, tqa);
+        tqb = __builtin_fma(V[5], w1, tqb);
+        tqa = __builtin_fma(V[6], t2, tqa);
+        tqb = __builtin_fma(V[7], w2, tqb);
+        // theta_{t+1} needs thetadot_t only: its sin / cos and the neighbour exchange run
+        // beside this step's solve (software pipelining across steps, swimmer_quad3.h)
+        const double th_next = __builtin_fma(C.h, thd, th);
+        Gx = sw::quad3_geometry(th_next);
+        const double det = sw::quad3_dynamics(C, L, Gc, gdx, gdy, thd, w1, w2, tqa + tqb);
+        th = th_next;
         asm("v_min_f64 %0, %1, %2" : "=v"(detmin) : "v"(detmin), "v"(det));
-        total += __builtin_fma(gdx, C.dirx, gdy * C.diry);
-        const double gsel = __builtin_fma(L.gx, gdx, L.gy * gdy);
+        // the return comes out of the per-component sums in the epilogue (linearity), no
+        // per-step reward arithmetic
+        const double gsel = __builtin_fma(selx, gdx, sely * gdy);
+        m1g += gsel;
         if (TRAJ) {
             store_cell(th, off_th);
             store_cell(thd, off_thd);
@@ -469,14 +492,20 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
             m2th = __builtin_fma(a, a, m2th);
             m1thd += thd;
             m2thd = __builtin_fma(thd, thd, m2thd);
-            m1g += gsel;
             m2g = __builtin_fma(gsel, gsel, m2g);
         }
         t1 = sw::dpp_f64<sw::kDppNext1>(th);
         t2 = sw::dpp_f64<sw::kDppNext2>(th);
         w1 = sw::dpp_f64<sw::kDppNext1>(thd);
         w2 = sw::dpp_f64<sw::kDppNext2>(thd);
+    };
+    // two steps per trip, the geometry ping-pongs between G and Gn (no register copies)
+    int32_t t = 0;
+    for (; t + 2 <= H; t += 2) {
+        one_step(G, Gn);
+        one_step(Gn, G);
     }
+    if (t < H) one_step(G, Gn);
 
     // ---- per-rollout outputs (quad lanes 0..2 hold the state; lane 0 the return) ----
     int code = ((detmin > 0.0) ? 0 : SW_STATUS_SINGULAR) |
@@ -484,7 +513,11 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
                ((thmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
     code |= __builtin_amdgcn_mov_dpp(code, sw::kDppNext1, 0xf, 0xf, true) |
             __builtin_amdgcn_mov_dpp(code, sw::kDppNext2, 0xf, 0xf, true);
+    // sum of the rewards Gdot_t . direction (remy_swimmer_env.py:238-243), by linearity:
+    // lane 0 holds sum Gdot_x, lane 1 sum Gdot_y
+    const double sgy = sw::dpp_f64<sw::kDppNext1>(m1g);
     if (valid && q == 0) {
+        const double total = __builtin_fma(C.dirx, m1g, C.diry * sgy);
         returns[r] = (code & SW_STATUS_RANGE) ? __builtin_nan("") : total;
         if (status) status[r] = code;
     }
@@ -544,7 +577,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
 
     // ---- this lane's policy row: V_i = c12 (W_{i-1} - W_i), W = (P +- nu delta) diag(inv_std)
     // (ars_agent.py:141-142, environment.py:32-34); u_{-1} = u_{n-1} = 0 (free ends)
-    double V[D], mu[D];
+    double V[D], nbias = 0.0;   // nbias = -V . mean: tq = V . (obs - mean) without per-step subtractions
     {
         const double *pl = ARS ? policies : policies + r * (M * D);
         const double *dl = ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr;
@@ -560,7 +593,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             const double up = (seg >= 1) ? entry(seg - 1, j) : 0.0;
             const double dn = (seg <= M - 1) ? entry(seg, j) : 0.0;
             V[j] = C.c12 * (up - dn);
-            mu[j] = mean ? mean[j] : 0.0;
+            if (mean) nbias = __builtin_fma(-V[j], mean[j], nbias);
         }
     }
 
@@ -578,7 +611,11 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     const uint32_t kDrop = 0xfffffff0u;
     const uint32_t off_th = (owner && valid) ? (uint32_t)(((int64_t)cth * n_roll + r) * 8) : kDrop;
     const uint32_t off_thd = (owner && valid) ? (uint32_t)(((int64_t)cthd * n_roll + r) * 8) : kDrop;
-    const uint32_t off_g = (q < 2 && valid) ? (uint32_t)(((int64_t)q * n_roll + r) * 8) : kDrop;
+    // Gdot is replicated (bit-identical on all lanes): lane 0 stores x, lane 1 stores y, with two
+    // store instructions.  (The quad kernel's per-lane select + single store has the same
+    // instruction count here but measured 5 % slower: the select lands on the serial chain.)
+    const uint32_t off_gx = (q == 0 && valid) ? (uint32_t)(r * 8) : kDrop;
+    const uint32_t off_gy = (q == 1 && valid) ? (uint32_t)((n_roll + r) * 8) : kDrop;
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
         traj, 0, TRAJ ? (int)(uint32_t)((int64_t)H * slab) : 0, 0x00020000);
     uint32_t soff = 0;
@@ -589,8 +626,9 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
     };
 
-    double total = 0.0, thmax = 0.0, pivmin_all = 1.0;
-    double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
+    double thmax = 0.0, pivmin_all = 1.0;
+    double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
+    double sgx = 0.0, sgy = 0.0, qgx = 0.0, qgy = 0.0;   // sums of Gdot and Gdot^2 over the steps
     double thk[N], wk[N];
     sw::RowGather<N>::run(th, thk);
     sw::RowGather<N>::run(thd, wk);
@@ -599,20 +637,26 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean); thk / wk
         // (every segment's angle / angular velocity) were gathered at the end of the previous
         // step, behind its stores and moment updates
-        double tq0 = V[0] * (gdx - mu[0]), tq1 = V[1] * (gdy - mu[1]);
+        double tq0 = __builtin_fma(V[0], gdx, nbias), tq1 = V[1] * gdy;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            tq0 = __builtin_fma(V[2 + 2 * k], thk[k] - mu[2 + 2 * k], tq0);
-            tq1 = __builtin_fma(V[3 + 2 * k], wk[k] - mu[3 + 2 * k], tq1);
+            tq0 = __builtin_fma(V[2 + 2 * k], thk[k], tq0);
+            tq1 = __builtin_fma(V[3 + 2 * k], wk[k], tq1);
         }
-        const double rq = sw::row_step<N>(C, L, gdx, gdy, th, thd, wk, tq0 + tq1);
+        // (no cross-step pipelining of the geometry here, unlike the quad kernel: the extra
+        // live sin / cos arrays push n >= 6 past 256 VGPRs, measured by instruction count)
+        const sw::RowGeo<N> G = sw::row_geometry<N>(th);
+        th = __builtin_fma(C.h, thd, th);            // explicit Euler: the OLD thetadot
+        const double rq = sw::row_dynamics<N>(C, L, G, gdx, gdy, thd, wk, tq0 + tq1);
         asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
-        total += __builtin_fma(gdx, C.dirx, gdy * C.diry);
-        const double gsel = __builtin_fma(L.gx, gdx, L.gy * gdy);
+        // the return comes out of the per-component sums in the epilogue (linearity)
+        sgx += gdx;
+        sgy += gdy;
         if (TRAJ) {
             store_cell(th, off_th);
             store_cell(thd, off_thd);
-            store_cell(gsel, off_g);
+            store_cell(gdx, off_gx);
+            store_cell(gdy, off_gy);
             soff += slab;
         }
         if (MOM) {
@@ -621,8 +665,8 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             m2th = __builtin_fma(a, a, m2th);
             m1thd += thd;
             m2thd = __builtin_fma(thd, thd, m2thd);
-            m1g += gsel;
-            m2g = __builtin_fma(gsel, gsel, m2g);
+            qgx = __builtin_fma(gdx, gdx, qgx);
+            qgy = __builtin_fma(gdy, gdy, qgy);
         }
         sw::RowGather<N>::run(th, thk);
         sw::RowGather<N>::run(thd, wk);
@@ -646,6 +690,8 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
                          ((nbad == 0.0) ? 0 : SW_STATUS_NONFINITE) |
                          ((tmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
         if (valid && q == 0) {
+            // sum of the rewards Gdot_t . direction (remy_swimmer_env.py:238-243), by linearity
+            const double total = __builtin_fma(C.dirx, sgx, C.diry * sgy);
             returns[r] = (code & SW_STATUS_RANGE) ? __builtin_nan("") : total;
             if (status) status[r] = code;
         }
@@ -657,6 +703,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     }
     if (MOM) {
         __shared__ double shm[kRowBlock / kWave][16][6];
+        double m1g = (q == 0) ? sgx : sgy, m2g = (q == 0) ? qgx : qgy;   // lane 0: x, lane 1: y
         if (!valid || !owner) m1th = m2th = m1thd = m2thd = m1g = m2g = 0.0;
         // sum over the 4 rows of the wave (lane bits 4, 5), then over the 4 waves through LDS
 #pragma unroll

@@ -54,7 +54,6 @@ struct Quad3Lane {
     double a0, a1, a2;      // Aw(i,i), Aw(i,i1), Aw(i,i2)
     double t1, t2, t12;     // -6 T(i,i1), -6 T(i,i2), -6 T(i1,i2)
     double d0, d12, d1, d2; // diagonal of Q in rotated order, d12 = d1*d2
-    double gx, gy;          // Gdot component this lane records: x on segment 0, y on 1 and 2
 };
 
 __device__ __forceinline__ Quad3Lane quad3_lane(int seg)
@@ -77,60 +76,77 @@ __device__ __forceinline__ Quad3Lane quad3_lane(int seg)
     L.d1 = pick(D2, D3, D1);
     L.d2 = pick(D3, D1, D2);
     L.d12 = L.d1 * L.d2;
-    L.gx = pick(1.0, 0.0, 0.0);
-    L.gy = pick(0.0, 1.0, 1.0);
     return L;
 }
 
-// One explicit-Euler step of one rollout spread over a quad.  On entry/exit: gdx, gdy
-// replicated, th/thd own segment.  w1, w2: the neighbours' angular velocities (the caller
-// exchanged them for the policy already); tq_scaled = 12/(m l^2) (u_{i-1} - u_i), this
-// segment's joint-torque balance.  Returns det of the (rotated) system for the singularity check.
-__device__ __forceinline__ double quad3_step(const Consts &C, const Quad3Lane &L, double &gdx,
-                                             double &gdy, double &th, double &thd, double w1,
-                                             double w2, double tq_scaled)
+// Everything of a step that depends on the angles only: own and neighbours' sin / cos and the
+// pairwise cos(th_i - th_k), sin(th_k - th_i).  theta_{t+1} = theta_t + h thetadot_t is known
+// at the START of step t, so the caller evaluates the geometry of step t+1 while step t's
+// solve is still in flight: the sincos chain (the longest dependent chain of the step) leaves
+// the critical path thetadot_t -> thetadot_{t+1}.
+struct Quad3Geo {
+    double s, c, s1, c1, s2, c2;   // own, next1, next2
+    double cc1, cc2, cc12;         // cos(th_i - th_i1), cos(th_i - th_i2), cos(th_i1 - th_i2)
+    double ss1, ss2;               // sin(th_i1 - th_i), sin(th_i2 - th_i)
+};
+
+__device__ __forceinline__ Quad3Geo quad3_geometry(double th)
 {
-    double s, c;
-    sincos_fast(th, s, c);
-    // neighbours' sin, cos
-    const double s1 = dpp_f64<kDppNext1>(s), c1 = dpp_f64<kDppNext1>(c);
-    const double s2 = dpp_f64<kDppNext2>(s), c2 = dpp_f64<kDppNext2>(c);
-    // cos(th_i - th_k), sin(th_k - th_i)
-    const double cc1 = __builtin_fma(c, c1, s * s1), cc2 = __builtin_fma(c, c2, s * s2);
-    const double cc12 = __builtin_fma(c1, c2, s1 * s2);
-    const double ss1 = __builtin_fma(c, s1, -s * c1), ss2 = __builtin_fma(c, s2, -s * c2);
+    Quad3Geo G;
+    sincos_fast(th, G.s, G.c);
+    G.s1 = dpp_f64<kDppNext1>(G.s);
+    G.c1 = dpp_f64<kDppNext1>(G.c);
+    G.s2 = dpp_f64<kDppNext2>(G.s);
+    G.c2 = dpp_f64<kDppNext2>(G.c);
+    G.cc1 = __builtin_fma(G.c, G.c1, G.s * G.s1);
+    G.cc2 = __builtin_fma(G.c, G.c2, G.s * G.s2);
+    G.cc12 = __builtin_fma(G.c1, G.c2, G.s1 * G.s2);
+    G.ss1 = __builtin_fma(G.c, G.s1, -G.s * G.c1);
+    G.ss2 = __builtin_fma(G.c, G.s2, -G.s * G.c2);
+    return G;
+}
+
+// The velocity-dependent part of one explicit-Euler step of one rollout spread over a quad:
+// updates gdx, gdy (replicated) and thd (own segment); theta is advanced by the caller.
+// w1, w2: the neighbours' angular velocities (the caller exchanged them for the policy
+// already); tq_scaled = 12/(m l^2) (u_{i-1} - u_i), this segment's joint-torque balance.
+// Returns det of the (rotated) system for the singularity check.
+__device__ __forceinline__ double quad3_dynamics(const Consts &C, const Quad3Lane &L,
+                                                 const Quad3Geo &G, double &gdx, double &gdy,
+                                                 double &thd, double w1, double w2,
+                                                 double tq_scaled)
+{
     // normal velocity of this segment's centre
-    double g = __builtin_fma(gdy, c, -gdx * s);
+    double g = __builtin_fma(gdy, G.c, -gdx * G.s);
     g = __builtin_fma(L.vw0 * C.l, thd, g);
-    g = __builtin_fma((L.vw1 * C.l) * cc1, w1, g);
-    g = __builtin_fma((L.vw2 * C.l) * cc2, w2, g);
+    g = __builtin_fma((L.vw1 * C.l) * G.cc1, w1, g);
+    g = __builtin_fma((L.vw2 * C.l) * G.cc2, w2, g);
     const double g1 = dpp_f64<kDppNext1>(g), g2 = dpp_f64<kDppNext2>(g);
-    // barycentre acceleration (rotated summation order; re-synchronised by the caller)
-    const double sx = __builtin_fma(g2, s2, __builtin_fma(g1, s1, g * s));
-    const double sy = __builtin_fma(g2, c2, __builtin_fma(g1, c1, g * c));
-    const double gddx = C.kl_nm * sx, gddy = -C.kl_nm * sy;
+    // barycentre acceleration (rotated summation order; re-synchronised below)
+    const double sx = __builtin_fma(g2, G.s2, __builtin_fma(g1, G.s1, g * G.s));
+    const double sy = __builtin_fma(g2, G.c2, __builtin_fma(g1, G.c1, g * G.c));
     // this segment's row of Q thdd = r
-    double cent = (L.t1 * (w1 * w1)) * ss1;
-    cent = __builtin_fma(L.t2 * (w2 * w2), ss2, cent);
+    double cent = (L.t1 * (w1 * w1)) * G.ss1;
+    cent = __builtin_fma(L.t2 * (w2 * w2), G.ss2, cent);
     double fric = L.a0 * g;
-    fric = __builtin_fma(L.a1 * cc1, g1, fric);
-    fric = __builtin_fma(L.a2 * cc2, g2, fric);
+    fric = __builtin_fma(L.a1 * G.cc1, g1, fric);
+    fric = __builtin_fma(L.a2 * G.cc2, g2, fric);
     double r0 = __builtin_fma(-C.six_k_m, fric, cent);
     r0 = __builtin_fma(C.kl_m, thd, r0);
     r0 += tq_scaled;
     const double r1 = dpp_f64<kDppNext1>(r0), r2 = dpp_f64<kDppNext2>(r0);
     // first row of the adjugate of [[d0,a,b],[a,d1,e],[b,e,d2]]
-    const double a = L.t1 * cc1, b = L.t2 * cc2, e = L.t12 * cc12;
+    const double a = L.t1 * G.cc1, b = L.t2 * G.cc2, e = L.t12 * G.cc12;
     const double c00 = __builtin_fma(-e, e, L.d12);
     const double c01 = __builtin_fma(b, e, -a * L.d2);
     const double c02 = __builtin_fma(a, e, -b * L.d1);
     const double det = __builtin_fma(L.d0, c00, __builtin_fma(a, c01, b * c02));
     const double num = __builtin_fma(c00, r0, __builtin_fma(c01, r1, c02 * r2));
-    const double tdd = num * rcp_f64(det);
-    // explicit Euler (remy_swimmer_env.py:87-91)
-    gdx = __builtin_fma(C.h, gddx, gdx);
-    gdy = __builtin_fma(C.h, gddy, gdy);
-    th = __builtin_fma(C.h, thd, th);
+    const double tdd = num * rcp_f64_1n(det);
+    // explicit Euler (remy_swimmer_env.py:87-91); Gddot = (k l / (n m)) (sx, -sy), folded with
+    // h into one FMA per component
+    gdx = __builtin_fma(C.h_kl_nm, sx, gdx);
+    gdy = __builtin_fma(-C.h_kl_nm, sy, gdy);
     thd = __builtin_fma(C.h, tdd, thd);
     // one authoritative Gdot per rollout: lane 0's
     gdx = dpp_f64<kDppLane0>(gdx);

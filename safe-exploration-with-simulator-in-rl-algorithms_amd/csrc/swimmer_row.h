@@ -46,7 +46,6 @@ struct RowLane {
     double one[N];    // 1 at k = i
     double below[N];  // 1 where i > k   (elimination step k updates this lane)
     double above[N];  // 1 where i < k   (back-substitution step k updates this lane)
-    double gx, gy;    // Gdot component recorded by this lane (x on segment 0, y otherwise)
 };
 
 template <int N>
@@ -75,8 +74,6 @@ __device__ __forceinline__ RowLane<N> row_lane(const Consts &C, int seg)
     for (int ii = 0; ii < N; ++ii)
         if (seg == ii) qd = -6.0 * Tw<N>(ii + 1, ii + 1) + 1.0;
     L.qd = qd;
-    L.gx = (seg == 0) ? 1.0 : 0.0;
-    L.gy = (seg == 0) ? 0.0 : 1.0;
     return L;
 }
 
@@ -100,7 +97,7 @@ template <int N, int J = 0>
 struct RowEliminate {
     static __device__ __forceinline__ void run(const RowLane<N> &L, double (&a)[N], double &b, double &rq)
     {
-        const double rp = rcp_f64(row_bcast<J>(a[J]));
+        const double rp = rcp_f64_1n(row_bcast<J>(a[J]));
         rq = __builtin_fma(L.one[J], rp, rq);          // lane J keeps 1 / Q_JJ
         if (J < N - 1) {
             const double f = (L.below[J] * a[J]) * rp;  // Q_iJ / Q_JJ on lanes i > J, else 0
@@ -135,30 +132,44 @@ struct RowBackSub<N, -1> {
     static __device__ __forceinline__ void run(const RowLane<N> &, const double (&)[N], double &, double) {}
 };
 
-// One explicit-Euler step.  gdx, gdy: replicated (bit-identical on all lanes); th, thd: own
-// segment; wk: every segment's thetadot (already gathered by the caller for the policy);
+// Every segment's sin / cos, gathered in canonical order (the angle-only part of a step).
+template <int N>
+struct RowGeo {
+    double s, c;            // own segment
+    double sk[N], ck[N];    // every segment, canonical order
+};
+
+template <int N>
+__device__ __forceinline__ RowGeo<N> row_geometry(double th)
+{
+    RowGeo<N> G;
+    sincos_fast(th, G.s, G.c);
+    RowGather<N>::run(G.s, G.sk);
+    RowGather<N>::run(G.c, G.ck);
+    return G;
+}
+
+// The velocity-dependent part of one explicit-Euler step: updates gdx, gdy (replicated,
+// bit-identical on all lanes) and thd (own segment); theta is advanced by the caller.
+// wk: every segment's thetadot (already gathered by the caller for the policy);
 // tq_scaled = c12 (u_{i-1} - u_i) for this lane's segment.  Returns this lane's reciprocal
 // pivot (positive for a positive definite system).
 template <int N>
-__device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L, double &gdx,
-                                           double &gdy, double &th, double &thd,
-                                           const double (&wk)[N], double tq_scaled)
+__device__ __forceinline__ double row_dynamics(const Consts &C, const RowLane<N> &L,
+                                               const RowGeo<N> &G, double &gdx, double &gdy,
+                                               double &thd, const double (&wk)[N],
+                                               double tq_scaled)
 {
-    double s, c;
-    sincos_fast(th, s, c);
-    double sk[N], ck[N];
-    RowGather<N>::run(s, sk);
-    RowGather<N>::run(c, ck);
     // own row of cos(th_i - th_k), sin(th_k - th_i); the k = i entries come out as
     // c^2 + s^2 (= 1 to an ulp) and 0 and carry weight 1 resp. 0 below
     double cc[N], ss[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        cc[k] = __builtin_fma(c, ck[k], s * sk[k]);
-        ss[k] = __builtin_fma(c, sk[k], -s * ck[k]);
+        cc[k] = __builtin_fma(G.c, G.ck[k], G.s * G.sk[k]);
+        ss[k] = __builtin_fma(G.c, G.sk[k], -G.s * G.ck[k]);
     }
     // normal velocity of this segment's centre
-    double g = __builtin_fma(gdy, c, -gdx * s);
+    double g = __builtin_fma(gdy, G.c, -gdx * G.s);
 #pragma unroll
     for (int k = 0; k < N; ++k) g = __builtin_fma(L.vwl[k] * cc[k], wk[k], g);
     double gk[N];
@@ -167,10 +178,9 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
     double sx = 0.0, sy = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        sx = __builtin_fma(gk[k], sk[k], sx);
-        sy = __builtin_fma(gk[k], ck[k], sy);
+        sx = __builtin_fma(gk[k], G.sk[k], sx);
+        sy = __builtin_fma(gk[k], G.ck[k], sy);
     }
-    const double gddx = C.kl_nm * sx, gddy = -C.kl_nm * sy;
     // right-hand side of this segment's row
     double r = __builtin_fma(C.kl_m, thd, tq_scaled);
 #pragma unroll
@@ -186,9 +196,9 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
     RowEliminate<N>::run(L, a, r, rq);
     RowBackSub<N>::run(L, a, r, rq);
     const double tdd = r * rq;
-    gdx = __builtin_fma(C.h, gddx, gdx);
-    gdy = __builtin_fma(C.h, gddy, gdy);
-    th = __builtin_fma(C.h, thd, th);
+    // Gddot = (k l / (n m)) (sx, -sy), folded with h into one FMA per component
+    gdx = __builtin_fma(C.h_kl_nm, sx, gdx);
+    gdy = __builtin_fma(-C.h_kl_nm, sy, gdy);
     thd = __builtin_fma(C.h, tdd, thd);
     return rq;
 }
