@@ -629,25 +629,11 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     double thmax = 0.0, pivmin_all = 1.0;
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
     double sgx = 0.0, sgy = 0.0, qgx = 0.0, qgy = 0.0;   // sums of Gdot and Gdot^2 over the steps
-    double thk[N], wk[N];
-    sw::RowGather<N>::run(th, thk);
-    sw::RowGather<N>::run(thd, wk);
     for (int32_t t = 0; t < H; ++t) {
         asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
-        // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean); thk / wk
-        // (every segment's angle / angular velocity) were gathered at the end of the previous
-        // step, behind its stores and moment updates
-        double tq0 = __builtin_fma(V[0], gdx, nbias), tq1 = V[1] * gdy;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            tq0 = __builtin_fma(V[2 + 2 * k], thk[k], tq0);
-            tq1 = __builtin_fma(V[3 + 2 * k], wk[k], tq1);
-        }
-        // (no cross-step pipelining of the geometry here, unlike the quad kernel: the extra
-        // live sin / cos arrays push n >= 6 past 256 VGPRs, measured by instruction count)
-        const sw::RowGeo<N> G = sw::row_geometry<N>(th);
-        th = __builtin_fma(C.h, thd, th);            // explicit Euler: the OLD thetadot
-        const double rq = sw::row_dynamics<N>(C, L, G, gdx, gdy, thd, wk, tq0 + tq1);
+        // policy + physics of one step (swimmer_row.h); the other segments' angles and angular
+        // velocities are read straight out of their lanes by fused broadcast-FMAs
+        const double rq = sw::row_step<N>(C, L, V, nbias, gdx, gdy, th, thd);
         asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
         // the return comes out of the per-component sums in the epilogue (linearity)
         sgx += gdx;
@@ -668,8 +654,6 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             qgx = __builtin_fma(gdx, gdx, qgx);
             qgy = __builtin_fma(gdy, gdy, qgy);
         }
-        sw::RowGather<N>::run(th, thk);
-        sw::RowGather<N>::run(thd, wk);
     }
 
     // ---- per-rollout outputs ----
