@@ -205,8 +205,12 @@ struct RowFused;   // specialised for N = 4 .. 8 below
 '''
 
 
+def render():
+    return HEADER + "".join(gen(n) for n in range(4, 9)) + "}  // namespace sw\n"
+
+
 def main():
-    text = HEADER + "".join(gen(n) for n in range(4, 9)) + "}  // namespace sw\n"
+    text = render()
     with open(OUT, "w") as f:
         f.write(text)
     print("wrote", OUT, len(text.splitlines()), "lines")
