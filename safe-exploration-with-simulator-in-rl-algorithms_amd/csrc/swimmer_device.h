@@ -100,7 +100,22 @@ __device__ __forceinline__ double fma3_sc(double a, double b, double coef)
     return d;
 }
 
-__device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_out)
+// The leading coefficients of the two kernels: the first Horner step is fma(K, z, C) with two
+// constants, and only one of them can come from a scalar register.  Rollout kernels create this
+// pair once, before the step loop (trig_consts() makes the values opaque, so the compiler keeps
+// them in VGPRs instead of re-materialising them with a v_mov per evaluation).
+struct TrigK {
+    double s6, c6;
+};
+
+__device__ __forceinline__ TrigK trig_consts()
+{
+    TrigK k{1.58969099521155010221e-10, -1.13596475577881948265e-11};
+    asm volatile("" : "+v"(k.s6), "+v"(k.c6));
+    return k;
+}
+
+__device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_out, const TrigK &K)
 {
     const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: integer part lands in the low bits
     const double kd_m = __builtin_fma(x, 0.63661977236758134308, MAGIC);
@@ -109,12 +124,12 @@ __device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_o
     double r = __builtin_fma(-kd, 1.5707963267948966, x);       // exact
     r = __builtin_fma(-kd, 6.123233995736766e-17, r);
     const double z = r * r;
-    double ps = fma3_sc(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+    double ps = fma3_sc(K.s6, z, -2.50507602534068634195e-08);
     ps = fma3_sc(ps, z, 2.75573137070700676789e-06);
     ps = fma3_sc(ps, z, -1.98412698298579493134e-04);
     ps = fma3_sc(ps, z, 8.33333333332248946124e-03);
     ps = fma3_sc(ps, z, -1.66666666666666324348e-01);
-    double pc = fma3_sc(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+    double pc = fma3_sc(K.c6, z, 2.08757232129817482790e-09);
     pc = fma3_sc(pc, z, -2.75573143513906633035e-07);
     pc = fma3_sc(pc, z, 2.48015872894767294178e-05);
     pc = fma3_sc(pc, z, -1.38888888888741095749e-03);
@@ -129,6 +144,11 @@ __device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_o
     const uint32_t sfl = w & 0x80000000u, cfl = (w ^ t31) & 0x80000000u;
     s_out = __hiloint2double((int)((uint32_t)__double2hiint(sv) ^ sfl), __double2loint(sv));
     c_out = __hiloint2double((int)((uint32_t)__double2hiint(cv) ^ cfl), __double2loint(cv));
+}
+
+__device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_out)
+{
+    sincos_fast(x, s_out, c_out, TrigK{1.58969099521155010221e-10, -1.13596475577881948265e-11});
 }
 
 // max(acc, |theta_i|): one v_max_f64 per angle; NaN angles are caught by the finiteness

@@ -455,7 +455,8 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
     // update that just wrote them
     double t1 = sw::dpp_f64<sw::kDppNext1>(th), t2 = sw::dpp_f64<sw::kDppNext2>(th);
     double w1 = sw::dpp_f64<sw::kDppNext1>(thd), w2 = sw::dpp_f64<sw::kDppNext2>(thd);
-    sw::Quad3Geo G = sw::quad3_geometry(th), Gn;
+    const sw::TrigK K = sw::trig_consts();
+    sw::Quad3Geo G = sw::quad3_geometry(th, K), Gn;
     // one step: consumes the geometry Gc of theta_t, produces Gx for theta_{t+1}
     auto one_step = [&](const sw::Quad3Geo &Gc, sw::Quad3Geo &Gx) {
         asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
@@ -472,7 +473,7 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         // theta_{t+1} needs thetadot_t only: its sin / cos and the neighbour exchange run
         // beside this step's solve (software pipelining across steps, swimmer_quad3.h)
         const double th_next = __builtin_fma(C.h, thd, th);
-        Gx = sw::quad3_geometry(th_next);
+        Gx = sw::quad3_geometry(th_next, K);
         const double det = sw::quad3_dynamics(C, L, Gc, gdx, gdy, thd, w1, w2, tqa + tqb);
         th = th_next;
         asm("v_min_f64 %0, %1, %2" : "=v"(detmin) : "v"(detmin), "v"(det));
@@ -629,11 +630,12 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     double thmax = 0.0, pivmin_all = 1.0;
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
     double sgx = 0.0, sgy = 0.0, qgx = 0.0, qgy = 0.0;   // sums of Gdot and Gdot^2 over the steps
+    const sw::TrigK K = sw::trig_consts();
     for (int32_t t = 0; t < H; ++t) {
         asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
         // policy + physics of one step (swimmer_row.h); the other segments' angles and angular
         // velocities are read straight out of their lanes by fused broadcast-FMAs
-        const double rq = sw::row_step<N>(C, L, V, nbias, gdx, gdy, th, thd);
+        const double rq = sw::row_step<N>(C, L, V, nbias, K, gdx, gdy, th, thd);
         asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
         // the return comes out of the per-component sums in the epilogue (linearity)
         sgx += gdx;

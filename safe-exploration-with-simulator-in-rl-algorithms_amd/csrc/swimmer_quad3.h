@@ -90,10 +90,10 @@ struct Quad3Geo {
     double ss1, ss2;               // sin(th_i1 - th_i), sin(th_i2 - th_i)
 };
 
-__device__ __forceinline__ Quad3Geo quad3_geometry(double th)
+__device__ __forceinline__ Quad3Geo quad3_geometry(double th, const TrigK &K)
 {
     Quad3Geo G;
-    sincos_fast(th, G.s, G.c);
+    sincos_fast(th, G.s, G.c, K);
     G.s1 = dpp_f64<kDppNext1>(G.s);
     G.c1 = dpp_f64<kDppNext1>(G.c);
     G.s2 = dpp_f64<kDppNext2>(G.s);

@@ -128,11 +128,12 @@ struct RowEliminate<N, N> {
 // reciprocal pivot (positive for a positive definite system).
 template <int N>
 __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
-                                           const double (&V)[2 * N + 2], double nbias, double &gdx,
-                                           double &gdy, double &th, double &thd)
+                                           const double (&V)[2 * N + 2], double nbias,
+                                           const TrigK &K, double &gdx, double &gdy, double &th,
+                                           double &thd)
 {
     double s, c;
-    sincos_fast(th, s, c);
+    sincos_fast(th, s, c, K);
     double sk[N], ck[N];
     RowGather<N>::run(s, sk);
     RowGather<N>::run(c, ck);
