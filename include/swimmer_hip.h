@@ -188,21 +188,25 @@ int sw_mt19937_uniform_pm1(uint32_t *key, int32_t *pos, int64_t n, double *out);
 
 /* ---- ARS iteration pipeline (host-side enqueue logic in native code) ------------------
  * Replaces the serial body of ARSAgent.runOneIteration (ars/ars_agent.py:137-182) with a
- * three-stream schedule over a ring of SW_PIPELINE_SLOTS buffer sets.  A pipeline owns two
- * extra HIP streams (copy, cov) and the events ordering them against the caller's stream;
- * it owns no device memory: every buffer is passed per call, one set per `slot`
- * (= iteration index mod SW_PIPELINE_SLOTS).  The caller's stream never waits on another
- * stream: ring depth + host-side event checks replace device-side waits.
+ * schedule over a ring of SW_PIPELINE_SLOTS buffer sets.  A pipeline owns one extra HIP stream
+ * (H2D copies of the deltas) and 64 bytes of pinned host memory (a progress flag); it owns no
+ * device memory: every buffer is passed per call, one set per `slot` (= iteration index mod
+ * SW_PIPELINE_SLOTS; use the pipeline with ONE stream).  The caller's stream carries kernels
+ * only -- no cross-stream waits, no event records: every rollout launch stores its index to the
+ * progress flag when it starts, and the host paces buffer reuse on that.
  *
  *   sw_ars_iteration_rollouts_f64   copy stream: deltas_host (pinned) -> deltas_dev
- *                                   caller's stream: the 2*n_dir rollouts of this rank's shard
- *                                   cov stream: sw_traj_moments_f64(traj) -> cov_acc (if given)
+ *                                   caller's stream: ONE launch = the 2*n_dir rollouts of this
+ *                                   rank's shard + (extra workgroups) the covariance pass
+ *                                   sw_traj_moments_f64 over the PREVIOUS call's traj -> its
+ *                                   cov_acc; this call's traj is owed a pass (if cov_acc given)
  *   ... caller all-gathers its segment [returns | moment rows] between ranks ...
  *   sw_ars_iteration_update_f64     caller's stream: sw_ars_update_gathered_f64 on the gathered
- *                                   buffer, then marks the slot free and launches the cov pass
+ *                                   buffer
  *
  * Before refilling deltas_host of a slot the host calls sw_ars_pipeline_host_slot_wait;
- * before reading cov_acc it calls sw_ars_pipeline_sync_cov. */
+ * before reading cov_acc it calls sw_ars_pipeline_sync_cov (runs the pass still owed and
+ * synchronises the stream). */
 #define SW_PIPELINE_SLOTS 4
 typedef struct sw_ars_pipeline sw_ars_pipeline;
 

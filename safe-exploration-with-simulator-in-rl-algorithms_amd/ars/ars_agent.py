@@ -90,10 +90,10 @@ class ARSAgent(object):
         # Ring-buffered pipeline (slot = iteration mod ring depth), enqueued from native code
         # (sw_ars_pipeline, include/swimmer_hip.h):
         #   copy stream : H2D of the deltas, overlaps the tail of the previous iteration
-        #   main stream : rollouts -> all-gather -> update   (the critical path)
-        #   cov stream  : full-covariance pass over the recorded trajectories, off the
-        #                 critical path (only diag(cov) feeds the policy, and that comes from
-        #                 the moments fused into the rollout kernel)
+        #   main stream : rollouts -> all-gather -> update   (the critical path, kernels only);
+        #                 the full-covariance pass over iteration i's trajectories rides along
+        #                 in the rollout launch of iteration i + 1 (only diag(cov) feeds the
+        #                 policy, and that comes from the moments fused into the rollout kernel)
         self._pipe = kernels.ArsPipeline()
         ring = self._pipe.slots
         self._deltas2 = [torch.empty((N, self.m, self.d), **f64) for _ in range(ring)]

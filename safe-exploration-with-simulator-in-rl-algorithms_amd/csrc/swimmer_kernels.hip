@@ -18,7 +18,8 @@
 //   ars_update_kernel          sigma_R, policy step, V2 statistics merge; pure latency between
 //                              two rollout launches: one round of loads, then LDS only
 //   traj_moments_kernel<D>     full first/second moments of a trajectory buffer; HBM-bound
-//   + the native ARS iteration pipeline (sw_ars_pipeline_*: three streams, 4-slot buffer ring)
+//   + the native ARS iteration pipeline (sw_ars_pipeline_*: copy stream, progress flag, 4-slot
+//     buffer ring; the covariance pass rides along in the next rollout launch, SideJob)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -369,6 +370,152 @@ rollout_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_roll, int32_t H, const 
     }
 }
 
+constexpr int kMomBlock = 256;
+constexpr int kMomTChunk = 32;  // steps per workgroup (8 measured slower: more atomics, less work per workgroup)
+
+// One tile of the full first / second moment sums of a trajectory buffer [H][D][n_roll]:
+// BLOCK rollouts x the steps [t0, t1), accumulated into acc = [count | sum x (D) | sum x x^T (D x D)]
+// (x = state - reset pivot) with atomics.  Workgroups of any size that is a multiple of 64 can
+// run it: the standalone traj_moments_kernel and the covariance workgroups that ride along in a
+// rollout launch (SideJob).  For long chains the upper triangle is accumulated JB rows at a time
+// (re-reading the tile from cache) so that the accumulators stay in registers.
+template <int D, int BLOCK, int J0, int JB>
+__device__ __forceinline__ void moments_pass(int64_t n_roll, const double *__restrict__ traj,
+                                             double *__restrict__ acc, int64_t bx, int32_t t0, int32_t t1,
+                                             double *sh /* [BLOCK / 64][D + JB * D] */)
+{
+    constexpr int NW = BLOCK / kWave, W = D + JB * D;
+    constexpr int J1 = (J0 + JB < D) ? J0 + JB : D;   // rows [J0, J1) of the upper triangle
+    const int64_t r = bx * BLOCK + threadIdx.x;
+    const int w = threadIdx.x / kWave, l = threadIdx.x % kWave;
+    double s1[D], s2[JB][D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) s1[j] = 0.0;
+#pragma unroll
+    for (int a = 0; a < JB; ++a)
+#pragma unroll
+        for (int g = 0; g < D; ++g) s2[a][g] = 0.0;
+    if (r < n_roll) {
+        for (int32_t t = t0; t < t1; ++t) {
+            const double *tp = traj + (int64_t)t * D * n_roll + r;
+            double x[D];
+#pragma unroll
+            for (int j = (J0 == 0 ? 0 : J0); j < D; ++j) {   // later passes need columns >= J0 only
+                const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
+                x[j] = tp[(int64_t)j * n_roll] - c;
+            }
+            if (J0 == 0) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) s1[j] += x[j];
+            }
+#pragma unroll
+            for (int f = J0; f < J1; ++f)
+#pragma unroll
+                for (int g = f; g < D; ++g) s2[f - J0][g] = __builtin_fma(x[f], x[g], s2[f - J0][g]);
+        }
+    }
+    __syncthreads();   // the previous pass has drained sh
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const bool live = (j < D) ? (J0 == 0) : (J0 + (j - D) / D < J1 && (j - D) % D >= J0 + (j - D) / D);
+        if (!live) continue;   // compile-time after unrolling
+        double v = (j < D) ? s1[j < D ? j : 0] : s2[(j >= D ? j - D : 0) / D][(j >= D ? j - D : 0) % D];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+        if (l == 0) sh[w * W + j] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < W; j += BLOCK) {
+        const int f = J0 + (j - D) / D, g = (j - D) % D;
+        const bool live = (j < D) ? (J0 == 0) : (f < J1 && g >= f);
+        if (!live) continue;
+        double v = 0.0;
+        for (int i = 0; i < NW; ++i) v += sh[i * W + j];
+        if (j < D) {
+            atomicAdd(&acc[1 + j], v);
+        } else {   // mirror into both halves
+            atomicAdd(&acc[1 + D + f * D + g], v);
+            if (g != f) atomicAdd(&acc[1 + D + g * D + f], v);
+        }
+    }
+}
+
+template <int D, int BLOCK, int JB, int J0 = 0>
+struct MomentsPasses {
+    static __device__ __forceinline__ void run(int64_t n_roll, const double *__restrict__ traj,
+                                               double *__restrict__ acc, int64_t bx, int32_t t0,
+                                               int32_t t1, double *sh)
+    {
+        if constexpr (J0 < D) {
+            moments_pass<D, BLOCK, J0, JB>(n_roll, traj, acc, bx, t0, t1, sh);
+            MomentsPasses<D, BLOCK, JB, J0 + JB>::run(n_roll, traj, acc, bx, t0, t1, sh);
+        }
+    }
+};
+
+template <int D, int BLOCK>
+__device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const double *__restrict__ traj,
+                                             double *__restrict__ acc, int64_t bx, int32_t t0, int32_t t1,
+                                             bool count_tile)
+{
+    // rows of the upper triangle per pass: as many as keep the accumulators (D + the rows' entries)
+    // plus one state inside 256 VGPRs -- one pass up to D = 12, 2 / 3 / 4 passes for D = 14 / 16 / 18
+    constexpr int JB = (D <= 12) ? D : (D == 14 ? 7 : (D == 16 ? 6 : 5));
+    __shared__ double sh[(BLOCK / kWave) * (D + JB * D)];
+    MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, acc, bx, t0, t1, sh);
+    if (threadIdx.x == 0 && count_tile) {
+        const int64_t nr = min<int64_t>(BLOCK, n_roll - bx * BLOCK);
+        atomicAdd(&acc[0], (double)nr * (double)H);
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kMomBlock)
+traj_moments_kernel(int64_t n_roll, int32_t H, const double *__restrict__ traj,
+                    double *__restrict__ acc)
+{
+    const int32_t t0 = blockIdx.y * kMomTChunk;
+    moments_tile<D, kMomBlock>(n_roll, H, traj, acc, blockIdx.x, t0, min(H, t0 + kMomTChunk),
+                               blockIdx.y == 0);
+}
+
+// What a rollout launch of the ARS pipeline carries besides its rollouts (both optional):
+//  * a progress flag: workgroup 0 stores flag_value to host-visible memory when it starts, i.e.
+//    "everything enqueued on this stream before this launch has completed".  The host paces
+//    itself on it, so the critical stream carries no event-record packets (measured: one costs
+//    ~4 us between two kernels);
+//  * the covariance pass over the PREVIOUS iteration's trajectories, run by extra workgroups
+//    behind the rollout workgroups of the same grid: no second queue, no cross-queue events
+//    (measured: a concurrent kernel on another queue costs the rollout launch ~5 us whatever
+//    its size).  Those workgroups finish long before the rollouts do.
+struct SideJob {
+    uint32_t *flag;
+    uint32_t flag_value;
+    uint32_t first_cov_block;   // = number of rollout workgroups; UINT32_MAX: no covariance pass
+    uint32_t cov_nbx;           // covariance tiles along the rollout axis
+    int32_t cov_tchunk;         // steps per covariance tile
+    int32_t cov_H;
+    int64_t cov_rolls;
+    const double *cov_traj;
+    double *cov_acc;
+};
+
+template <int D, int BLOCK>
+__device__ __forceinline__ void side_cov_tile(const SideJob &sj)
+{
+    const uint32_t b = blockIdx.x - sj.first_cov_block;
+    const uint32_t bx = b % sj.cov_nbx, by = b / sj.cov_nbx;
+    const int32_t t0 = (int32_t)by * sj.cov_tchunk;
+    moments_tile<D, BLOCK>(sj.cov_rolls, sj.cov_H, sj.cov_traj, sj.cov_acc, bx, t0,
+                           min(sj.cov_H, t0 + sj.cov_tchunk), by == 0);
+}
+
+__device__ __forceinline__ void side_flag(const SideJob &sj)
+{
+    if (sj.flag && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(sj.flag, sj.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------
 // n = 3, one segment per lane (swimmer_quad3.h): 16 rollouts per 64-thread workgroup.
 // TRAJ / MOM are compile-time so the hot loop carries no per-step uniform branches.
@@ -379,8 +526,21 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
                      const double *__restrict__ mean, const double *__restrict__ inv_std,
                      const double *__restrict__ state0, double *__restrict__ returns,
                      double *__restrict__ traj, double *__restrict__ final_state,
-                     double *__restrict__ moments, int32_t *__restrict__ status)
+                     double *__restrict__ moments, int32_t *__restrict__ status, SideJob side)
 {
+    side_flag(side);
+    if (blockIdx.x >= side.first_cov_block) {   // a covariance workgroup riding along (uniform)
+        side_cov_tile<8, kRollBlock>(side);
+        return;
+    }
+    // This wave's speed IS the iteration time, so it must not share its SIMD's issue slots with
+    // the covariance workgroups of the same launch (or, multi-GPU, the collective's waves):
+    // touching the last VGPR and the last AGPR makes the kernel allocate the SIMD's whole
+    // register file (512 per lane), i.e. exactly one wave of this kernel fits on a SIMD and
+    // nothing else does.  (s_setprio alone does not help: a 4-cycle f64 op of the other wave is
+    // not pre-empted.  Measured: 4.5-7.6 us per iteration.)
+    asm volatile("" ::: "v255", "a255");
+    __builtin_amdgcn_s_setprio(3);
     constexpr int D = 8, M = 2;
     const int lane = threadIdx.x;
     const int q = lane & 3;
@@ -563,8 +723,15 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
                    const double *__restrict__ mean, const double *__restrict__ inv_std,
                    const double *__restrict__ state0, double *__restrict__ returns,
                    double *__restrict__ traj, double *__restrict__ final_state,
-                   double *__restrict__ moments, int32_t *__restrict__ status)
+                   double *__restrict__ moments, int32_t *__restrict__ status, SideJob side)
 {
+    side_flag(side);
+    if (blockIdx.x >= side.first_cov_block) {   // a covariance workgroup riding along (uniform)
+        side_cov_tile<2 * N + 2, kRowBlock>(side);
+        return;
+    }
+    asm volatile("" ::: "v255", "a255");   // one wave per SIMD, as in the quad kernel
+    __builtin_amdgcn_s_setprio(3);
     constexpr int D = 2 * N + 2, M = N - 1;
     const int tid = threadIdx.x;
     const int q = tid & 15;                        // lane inside the row
@@ -919,73 +1086,6 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
 // Full moments of traj[H][D][R].  Workgroup (bx, by): rollouts bx*256.., steps by*TCHUNK..;
 // every load is a coalesced row segment; partial sums are reduced over the workgroup and
 // added to acc with fp64 atomics (d + d(d+1)/2 + 1 atomics per workgroup).
-constexpr int kMomBlock = 256;
-constexpr int kMomTChunk = 32;  // steps per workgroup (8 measured slower: more atomics, less work per workgroup)
-
-template <int D>
-__global__ void __launch_bounds__(kMomBlock)
-traj_moments_kernel(int64_t n_roll, int32_t H, const double *__restrict__ traj,
-                    double *__restrict__ acc)
-{
-    constexpr int NP = D * (D + 1) / 2;
-    __shared__ double sh[kMomBlock / kWave][D + NP];
-    const int64_t r = (int64_t)blockIdx.x * kMomBlock + threadIdx.x;
-    const int32_t t0 = blockIdx.y * kMomTChunk;
-    const int32_t t1 = min(H, t0 + kMomTChunk);
-    double s1[D], s2[NP];
-#pragma unroll
-    for (int j = 0; j < D; ++j) s1[j] = 0.0;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) s2[j] = 0.0;
-    if (r < n_roll) {
-        for (int32_t t = t0; t < t1; ++t) {
-            const double *tp = traj + (int64_t)t * D * n_roll + r;
-            double x[D];
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
-                x[j] = tp[(int64_t)j * n_roll] - c;
-            }
-            int q = 0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                s1[j] += x[j];
-#pragma unroll
-                for (int g = j; g < D; ++g) {
-                    s2[q] = __builtin_fma(x[j], x[g], s2[q]);
-                    ++q;
-                }
-            }
-        }
-    }
-    const int w = threadIdx.x / kWave, l = threadIdx.x % kWave;
-#pragma unroll
-    for (int j = 0; j < D + NP; ++j) {
-        double v = (j < D) ? s1[j < D ? j : 0] : s2[j >= D ? j - D : 0];
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-        if (l == 0) sh[w][j] = v;
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < D + NP; j += kMomBlock) {
-        double v = 0.0;
-        for (int i = 0; i < kMomBlock / kWave; ++i) v += sh[i][j];
-        if (j < D) {
-            atomicAdd(&acc[1 + j], v);
-        } else {
-            // unpack upper-triangle index -> (f, g), mirror into both halves
-            int q = j - D, f = 0;
-            while (q >= D - f) { q -= D - f; ++f; }
-            const int g = f + q;
-            atomicAdd(&acc[1 + D + f * D + g], v);
-            if (g != f) atomicAdd(&acc[1 + D + g * D + f], v);
-        }
-    }
-    if (threadIdx.x == 0 && blockIdx.y == 0) {
-        const int64_t nr = min<int64_t>(kMomBlock, n_roll - (int64_t)blockIdx.x * kMomBlock);
-        atomicAdd(&acc[0], (double)nr * (double)H);
-    }
-}
 
 // ---- dispatch on the segment count -------------------------------------------------
 #define SW_DISPATCH_N(n, CALL)                 \
@@ -1074,6 +1174,23 @@ bool use_row(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
 int launch_status()
 {
     return hipGetLastError() == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
+}
+
+const SideJob kNoSide{nullptr, 0u, UINT32_MAX, 1u, 0, 0, 0, nullptr, nullptr};
+
+// Attach a covariance pass over (cov_traj, cov_rolls, cov_H) to a launch of `roll_blocks` rollout
+// workgroups of `block` threads; returns the number of extra workgroups.
+unsigned side_attach_cov(SideJob &sj, unsigned roll_blocks, int block)
+{
+    sj.first_cov_block = roll_blocks;
+    if (!sj.cov_traj || sj.cov_rolls <= 0 || sj.cov_H <= 0) {
+        sj.first_cov_block = UINT32_MAX;
+        return 0;
+    }
+    sj.cov_nbx = (uint32_t)((sj.cov_rolls + block - 1) / block);
+    sj.cov_tchunk = (block >= kMomBlock) ? kMomTChunk : kMomTChunk * (kMomBlock / block) / 2;
+    const unsigned ny = (unsigned)((sj.cov_H + sj.cov_tchunk - 1) / sj.cov_tchunk);
+    return sj.cov_nbx * ny;
 }
 
 }  // namespace
@@ -1184,14 +1301,14 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
         SW_DISPATCH_QUAD(false, traj != nullptr, moments != nullptr,
                          (hipStream_t)stream, C, n_roll, H, policies, (const double *)nullptr,
                          (int64_t)0, 0.0, mean, inv_std, state0, returns, traj, final_state,
-                         moments, status);
+                         moments, status, kNoSide);
         return launch_status();
     }
     if (use_row(p, n_roll, H, traj != nullptr)) {
         const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
         SW_DISPATCH_ROW(p->n, false, traj != nullptr, moments != nullptr, (hipStream_t)stream, C,
                         n_roll, H, policies, (const double *)nullptr, (int64_t)0, 0.0, mean,
-                        inv_std, state0, returns, traj, final_state, moments, status);
+                        inv_std, state0, returns, traj, final_state, moments, status, kNoSide);
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
@@ -1212,32 +1329,43 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
     return launch_status();
 }
 
-int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, int32_t H,
-                        const double *policy, const double *deltas, double nu, const double *mean,
-                        const double *inv_std, double *returns, double *traj, double *moments,
-                        int32_t *status, void *stream)
+// side: what the launch carries besides the rollouts (pipeline only); *side_taken tells whether
+// the chosen kernel could take it (the segment-per-lane kernels can, the lane kernel cannot).
+static int launch_ars_rollouts(const sw_params *p, int64_t dir_begin, int64_t n_dir, int32_t H,
+                               const double *policy, const double *deltas, double nu,
+                               const double *mean, const double *inv_std, double *returns,
+                               double *traj, double *moments, int32_t *status, void *stream,
+                               const SideJob *side, bool *side_taken)
 {
     int rc = check_params(p);
     if (rc) return rc;
     if (n_dir < 0 || H < 0 || dir_begin < 0) return SW_ERR_SIZE;
+    if (side_taken) *side_taken = false;
     if (n_dir == 0) return SW_OK;
     if (!policy || !deltas || !returns) return SW_ERR_NULL;
     if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
     const int64_t n_roll = 2 * n_dir;
     if (use_quad3(p, n_roll, H, traj != nullptr)) {
-        const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        SideJob sj = side ? *side : kNoSide;
+        grid += side_attach_cov(sj, grid, kRollBlock);
+        if (side_taken) *side_taken = side != nullptr;
         SW_DISPATCH_QUAD(true, traj != nullptr, moments != nullptr,
                          (hipStream_t)stream, C, n_roll, H, policy, deltas, dir_begin, nu, mean,
                          inv_std, (const double *)nullptr, returns, traj, (double *)nullptr,
-                         moments, status);
+                         moments, status, sj);
         return launch_status();
     }
     if (use_row(p, n_roll, H, traj != nullptr)) {
-        const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        SideJob sj = side ? *side : kNoSide;
+        grid += side_attach_cov(sj, grid, kRowBlock);
+        if (side_taken) *side_taken = side != nullptr;
         SW_DISPATCH_ROW(p->n, true, traj != nullptr, moments != nullptr, (hipStream_t)stream, C,
                         n_roll, H, policy, deltas, dir_begin, nu, mean, inv_std,
-                        (const double *)nullptr, returns, traj, (double *)nullptr, moments, status);
+                        (const double *)nullptr, returns, traj, (double *)nullptr, moments, status,
+                        sj);
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
@@ -1256,6 +1384,15 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
                                                moments, status));
     }
     return launch_status();
+}
+
+int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, int32_t H,
+                        const double *policy, const double *deltas, double nu, const double *mean,
+                        const double *inv_std, double *returns, double *traj, double *moments,
+                        int32_t *status, void *stream)
+{
+    return launch_ars_rollouts(p, dir_begin, n_dir, H, policy, deltas, nu, mean, inv_std, returns,
+                               traj, moments, status, stream, nullptr, nullptr);
 }
 
 static int launch_update(const sw_params *p, int64_t n_dir, const GatherView &gv,
@@ -1326,30 +1463,74 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
 }
 
 // ---- ARS iteration pipeline ---------------------------------------------------------
-// Host-side enqueue logic of one ARS iteration in native code: three streams and a ring of
-// SW_PIPELINE_SLOTS buffer slots per process, no device memory.
+// Host-side enqueue logic of one ARS iteration in native code: the caller's stream (the
+// critical path: rollouts -> [all-gather] -> update), a copy stream for the H2D of the deltas,
+// and a ring of SW_PIPELINE_SLOTS buffer slots per process.
 //
-// Measured on MI355X (profiles/): a device-side cross-stream wait in front of the rollout
-// kernel (hipStreamWaitEvent on the H2D copy or on the covariance pass) delays that kernel
-// by 13-18 us every iteration even when the awaited work finished long ago.  So the critical
-// stream carries NO device-side waits: the ring is deep enough that everything a rollout
-// launch depends on (its deltas' H2D, the covariance pass that last read its trajectory
-// slot, the update that last read its delta slot) completed iterations ago, and the host
-// merely confirms that (hipEventSynchronize, normally already satisfied) before enqueueing.
+// Measured on MI355X (profiles/), in the order the design reacted to it:
+//  * a device-side cross-stream wait in front of the rollout kernel (hipStreamWaitEvent on the
+//    H2D copy or on a covariance pass) delays that kernel by 13-18 us even when the awaited
+//    work finished long ago -> the critical stream carries NO device-side waits; the ring is
+//    deep enough that every dependency completed iterations earlier and the host only confirms;
+//  * an event RECORD between two kernels of the critical stream costs ~4 us -> none either:
+//    every rollout launch stores its index to a host-visible flag when it starts (SideJob),
+//    which tells the host that everything enqueued before it -- the previous update included --
+//    has completed;
+//  * a covariance pass launched as its own kernel on a side stream costs the concurrent rollout
+//    launch ~5 us whatever its size -> the pass over iteration i's trajectories rides along in
+//    the rollout launch of iteration i + 1 as extra workgroups (SideJob); the last one owed is
+//    flushed by sw_ars_pipeline_sync_cov.
 struct sw_ars_pipeline {
-    hipStream_t copy = nullptr, cov = nullptr;
-    hipEvent_t h2d_done[SW_PIPELINE_SLOTS] = {}, slot_free[SW_PIPELINE_SLOTS] = {},
-               cov_done[SW_PIPELINE_SLOTS] = {}, rolled = nullptr;
-    bool h2d_valid[SW_PIPELINE_SLOTS] = {}, free_valid[SW_PIPELINE_SLOTS] = {},
-         cov_valid[SW_PIPELINE_SLOTS] = {};
+    hipStream_t copy = nullptr;
+    hipEvent_t h2d_done[SW_PIPELINE_SLOTS] = {};
+    bool h2d_valid[SW_PIPELINE_SLOTS] = {};
+    uint32_t *flag_host = nullptr, *flag_dev = nullptr;   // progress flag (pinned, mapped)
+    uint32_t launches = 0;                                 // rollout launches issued so far
+    hipStream_t last_main = nullptr;
     int timing = 0;                                        // 0 off, k: time every k-th launch
-    int64_t launches = 0;
+    int64_t timing_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // around the sampled rollout launches
-    const double *cov_traj = nullptr;                      // covariance pass owed for this slot
+    // covariance pass owed: the trajectories of the latest rollout launch
+    const double *cov_traj = nullptr;
     double *cov_acc = nullptr;
     int64_t cov_rolls = 0;
     int32_t cov_H = 0;
+    sw_params cov_params = {};
 };
+
+namespace {
+
+__global__ void flag_kernel(uint32_t *flag, uint32_t value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Spin until the GPU has STARTED rollout launch number `need` (0-based) of this pipeline.
+int wait_flag(const sw_ars_pipeline *pl, uint32_t need)
+{
+    const volatile uint32_t *f = pl->flag_host;
+    for (int64_t spins = 0;; ++spins) {
+        if ((int32_t)(*f - need) >= 0) return SW_OK;
+        if ((spins & 0xfff) == 0xfff) {
+            // not hot any more: make sure the stream is still healthy instead of spinning forever
+            const hipError_t q = hipStreamQuery(pl->last_main);
+            if (q == hipSuccess) return ((int32_t)(*f - need) >= 0) ? SW_OK : SW_ERR_LAUNCH;
+            if (q != hipErrorNotReady) return SW_ERR_LAUNCH;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+int flush_owed_cov(sw_ars_pipeline *pl, hipStream_t stream)
+{
+    if (!pl->cov_traj) return SW_OK;
+    const int rc = sw_traj_moments_f64(&pl->cov_params, pl->cov_rolls, pl->cov_H, pl->cov_traj,
+                                       pl->cov_acc, stream);
+    pl->cov_traj = nullptr;
+    return rc;
+}
+
+}  // namespace
 
 int sw_ars_pipeline_create(sw_ars_pipeline **out)
 {
@@ -1358,12 +1539,14 @@ int sw_ars_pipeline_create(sw_ars_pipeline **out)
     if (!pl) return SW_ERR_LAUNCH;
     const unsigned evf = hipEventDisableTiming;
     bool ok = hipStreamCreateWithFlags(&pl->copy, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&pl->cov, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&pl->rolled, evf) == hipSuccess;
+              hipHostMalloc((void **)&pl->flag_host, 64, hipHostMallocMapped | hipHostMallocCoherent) ==
+                  hipSuccess;
+    if (ok) {
+        *pl->flag_host = 0u;
+        ok = hipHostGetDevicePointer((void **)&pl->flag_dev, pl->flag_host, 0) == hipSuccess;
+    }
     for (int i = 0; i < SW_PIPELINE_SLOTS && ok; ++i)
-        ok = hipEventCreateWithFlags(&pl->h2d_done[i], evf) == hipSuccess &&
-             hipEventCreateWithFlags(&pl->slot_free[i], evf) == hipSuccess &&
-             hipEventCreateWithFlags(&pl->cov_done[i], evf) == hipSuccess;
+        ok = hipEventCreateWithFlags(&pl->h2d_done[i], evf) == hipSuccess;
     if (!ok) {
         sw_ars_pipeline_destroy(pl);
         return SW_ERR_LAUNCH;
@@ -1376,48 +1559,45 @@ void sw_ars_pipeline_destroy(sw_ars_pipeline *pl)
 {
     if (!pl) return;
     if (pl->copy) (void)hipStreamSynchronize(pl->copy);
-    if (pl->cov) (void)hipStreamSynchronize(pl->cov);
+    if (pl->last_main) (void)hipStreamSynchronize(pl->last_main);   // kernels still write the flag
     for (auto &e : pl->timed) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    for (int i = 0; i < SW_PIPELINE_SLOTS; ++i) {
+    for (int i = 0; i < SW_PIPELINE_SLOTS; ++i)
         if (pl->h2d_done[i]) (void)hipEventDestroy(pl->h2d_done[i]);
-        if (pl->slot_free[i]) (void)hipEventDestroy(pl->slot_free[i]);
-        if (pl->cov_done[i]) (void)hipEventDestroy(pl->cov_done[i]);
-    }
-    if (pl->rolled) (void)hipEventDestroy(pl->rolled);
     if (pl->copy) (void)hipStreamDestroy(pl->copy);
-    if (pl->cov) (void)hipStreamDestroy(pl->cov);
+    if (pl->flag_host) (void)hipHostFree(pl->flag_host);
     delete pl;
 }
 
 int sw_ars_pipeline_slots(void) { return SW_PIPELINE_SLOTS; }
 
-// The host may refill deltas_host[slot] once the update that last read the slot's device
-// copy is done (which implies its H2D left the pinned buffer long before).
+// The host may refill deltas_host[slot] once the H2D copy that last read it has completed.
 int sw_ars_pipeline_host_slot_wait(sw_ars_pipeline *pl, int slot)
 {
     if (!pl) return SW_ERR_NULL;
     if (slot < 0 || slot >= SW_PIPELINE_SLOTS) return SW_ERR_SIZE;
     if (pl->h2d_valid[slot] && hipEventSynchronize(pl->h2d_done[slot]) != hipSuccess)
         return SW_ERR_LAUNCH;
-    if (pl->free_valid[slot] && hipEventSynchronize(pl->slot_free[slot]) != hipSuccess)
-        return SW_ERR_LAUNCH;
     return SW_OK;
 }
 
+// Everything the covariance accumulators are owed is in them when this returns.
 int sw_ars_pipeline_sync_cov(sw_ars_pipeline *pl)
 {
     if (!pl) return SW_ERR_NULL;
-    return hipStreamSynchronize(pl->cov) == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
+    if (!pl->last_main && !pl->cov_traj) return SW_OK;
+    const int rc = flush_owed_cov(pl, pl->last_main);
+    if (rc) return rc;
+    return hipStreamSynchronize(pl->last_main) == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
 }
 
 int sw_ars_pipeline_timing(sw_ars_pipeline *pl, int enable)
 {
     if (!pl) return SW_ERR_NULL;
     pl->timing = enable > 0 ? enable : 0;
-    pl->launches = 0;
+    pl->timing_launches = 0;
     if (enable) {
         for (auto &e : pl->timed) {
             (void)hipEventDestroy(e.first);
@@ -1456,43 +1636,75 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
     if (slot < 0 || slot >= SW_PIPELINE_SLOTS || n_dir_total < dir_begin + n_dir) return SW_ERR_SIZE;
     if (cov_acc && !traj && n_dir > 0) return SW_ERR_NULL;
     hipStream_t main = (hipStream_t)stream;
+    if (pl->last_main && pl->last_main != main) {
+        // the progress flag orders work on ONE stream; a new stream starts from a clean slate
+        if (hipStreamSynchronize(pl->last_main) != hipSuccess) return SW_ERR_LAUNCH;
+    }
+    pl->last_main = main;
     const size_t bytes = (size_t)n_dir_total * (size_t)((p->n - 1) * (2 * p->n + 2)) * sizeof(double);
-    // host-confirmed: nothing still reads this slot's device deltas (update of it - SLOTS)
-    if (pl->free_valid[slot] && hipEventSynchronize(pl->slot_free[slot]) != hipSuccess)
-        return SW_ERR_LAUNCH;
+    // Launch k reuses the buffers of launch k - SLOTS: its device deltas were last read by update
+    // k - SLOTS (done once launch k - SLOTS + 1 has started) and its trajectories by the
+    // covariance workgroups of launch k - SLOTS + 1 (done once launch k - SLOTS + 2 has started).
+    const uint32_t k = pl->launches;
+    if (k >= (uint32_t)SW_PIPELINE_SLOTS && n_dir > 0) {
+        rc = wait_flag(pl, k + 2u - (uint32_t)SW_PIPELINE_SLOTS);
+        if (rc) return rc;
+    }
     if (hipMemcpyAsync(deltas_dev, deltas_host, bytes, hipMemcpyHostToDevice, pl->copy) != hipSuccess)
         return SW_ERR_LAUNCH;
     if (hipEventRecord(pl->h2d_done[slot], pl->copy) != hipSuccess) return SW_ERR_LAUNCH;
     pl->h2d_valid[slot] = true;
-    // host-confirmed: the deltas have landed, and the covariance pass that last read this
-    // trajectory slot (it - SLOTS) is done -> the rollout launch needs no device-side wait
+    // host-confirmed: the deltas have landed -> the rollout launch needs no device-side wait
     if (hipEventSynchronize(pl->h2d_done[slot]) != hipSuccess) return SW_ERR_LAUNCH;
-    if (pl->cov_valid[slot] && hipEventSynchronize(pl->cov_done[slot]) != hipSuccess)
-        return SW_ERR_LAUNCH;
     if (n_dir > 0) {
         std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-        const bool timed_launch = pl->timing > 0 && (pl->launches++ % pl->timing) == 0;
+        const bool timed_launch = pl->timing > 0 && (pl->timing_launches++ % pl->timing) == 0;
         if (timed_launch) {
             if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess ||
                 hipEventRecord(ev.first, main) != hipSuccess)
                 return SW_ERR_LAUNCH;
         }
-        rc = sw_ars_rollouts_f64(p, dir_begin, n_dir, H, policy, deltas_dev, nu, mean, inv_std,
-                                 returns, traj, moments, status, stream);
+        SideJob sj = kNoSide;
+        sj.flag = pl->flag_dev;
+        sj.flag_value = k;
+        sj.cov_traj = pl->cov_traj;
+        sj.cov_acc = pl->cov_acc;
+        sj.cov_rolls = pl->cov_rolls;
+        sj.cov_H = pl->cov_H;
+        const bool cov_dims_match = pl->cov_traj && pl->cov_params.n == p->n;
+        if (!cov_dims_match) sj.cov_traj = nullptr;
+        bool taken = false;
+        if (!use_quad3(p, 2 * n_dir, H, traj != nullptr) && !use_row(p, 2 * n_dir, H, traj != nullptr)) {
+            // the lane kernel takes no side job: flag and owed covariance pass as launches of
+            // their own in front of it (not the fast path)
+            hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, main, pl->flag_dev, k);
+            rc = flush_owed_cov(pl, main);
+            if (rc) return rc;
+            sj = kNoSide;
+        } else if (pl->cov_traj && !cov_dims_match) {
+            rc = flush_owed_cov(pl, main);
+            if (rc) return rc;
+        }
+        rc = launch_ars_rollouts(p, dir_begin, n_dir, H, policy, deltas_dev, nu, mean, inv_std,
+                                 returns, traj, moments, status, stream, &sj, &taken);
         if (timed_launch) {
             (void)hipEventRecord(ev.second, main);
             pl->timed.push_back(ev);
         }
         if (rc) return rc;
+        if (taken && sj.cov_traj) pl->cov_traj = nullptr;   // rides along in this launch
+        pl->launches = k + 1u;
+        // this launch's trajectories are owed a covariance pass: the next launch carries it
+        if (cov_acc) {
+            rc = flush_owed_cov(pl, main);   // normally nothing left
+            if (rc) return rc;
+            pl->cov_traj = traj;
+            pl->cov_acc = cov_acc;
+            pl->cov_rolls = 2 * n_dir;
+            pl->cov_H = H;
+            pl->cov_params = *p;
+        }
     }
-    // The covariance pass over this iteration's trajectories is launched by
-    // sw_ars_iteration_update_f64, AFTER the update kernel: launched right behind the rollouts
-    // its ~500 workgroups queue in front of the update's 17 and triple the update's latency,
-    // which sits on the critical path; behind the update it overlaps the next rollouts.
-    pl->cov_traj = (cov_acc && n_dir > 0) ? traj : nullptr;
-    pl->cov_acc = cov_acc;
-    pl->cov_rolls = 2 * n_dir;
-    pl->cov_H = H;
     return SW_OK;
 }
 
@@ -1505,22 +1717,9 @@ int sw_ars_iteration_update_f64(sw_ars_pipeline *pl, int slot, const sw_params *
 {
     if (!pl) return SW_ERR_NULL;
     if (slot < 0 || slot >= SW_PIPELINE_SLOTS) return SW_ERR_SIZE;
-    int rc = sw_ars_update_gathered_f64(p, n_dir, gathered, world, chunk, rows_chunk, deltas_dev,
-                                        policy, alpha, b, top_b, running, n_new_states, mean,
-                                        inv_std, sigma_out, stream);
-    if (rc) return rc;
-    if (hipEventRecord(pl->slot_free[slot], (hipStream_t)stream) != hipSuccess) return SW_ERR_LAUNCH;
-    pl->free_valid[slot] = true;
-    if (pl->cov_traj) {
-        // slot_free also marks "rollouts of this slot done" for the cov stream
-        if (hipStreamWaitEvent(pl->cov, pl->slot_free[slot], 0) != hipSuccess) return SW_ERR_LAUNCH;
-        rc = sw_traj_moments_f64(p, pl->cov_rolls, pl->cov_H, pl->cov_traj, pl->cov_acc, pl->cov);
-        pl->cov_traj = nullptr;
-        if (rc) return rc;
-        if (hipEventRecord(pl->cov_done[slot], pl->cov) != hipSuccess) return SW_ERR_LAUNCH;
-        pl->cov_valid[slot] = true;
-    }
-    return SW_OK;
+    return sw_ars_update_gathered_f64(p, n_dir, gathered, world, chunk, rows_chunk, deltas_dev,
+                                      policy, alpha, b, top_b, running, n_new_states, mean,
+                                      inv_std, sigma_out, stream);
 }
 
 }  // extern "C"

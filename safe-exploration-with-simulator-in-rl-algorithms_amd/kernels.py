@@ -178,8 +178,9 @@ def traj_moments(p: SwParams, traj, acc=None):
 
 
 class ArsPipeline(object):
-    """Handle of a native sw_ars_pipeline (include/swimmer_hip.h): the double-buffered
-    copy / main / cov stream schedule of one ARS iteration, enqueued from C."""
+    """Handle of a native sw_ars_pipeline (include/swimmer_hip.h): the ring-buffered
+    copy stream + progress flag + ride-along covariance schedule of one ARS iteration,
+    enqueued from C."""
 
     def __init__(self):
         require_gpu()

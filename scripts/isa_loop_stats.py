@@ -6,7 +6,7 @@ import sys
 path, pat = sys.argv[1], sys.argv[2]
 lines = open(path).read().split('\n')
 start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\S*' + pat + r'\S*:', l))
-end = next(i for i in range(start, len(lines)) if 's_endpgm' in lines[i])
+end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
 body = lines[start:end + 1]
 labels = {}
 for i, l in enumerate(body):
