@@ -288,6 +288,31 @@ def test_ars_training_and_store(sw, golden, tmp_path):
     assert z["policies"].shape == (5 * 6, 2, 8) and z["trajectories"].shape == (5 * 6, 60, 8)
 
 
+@pytest.mark.parametrize("n,kernel", [(3, "auto"), (5, "auto"), (3, "lane"), (2, "auto")])
+def test_pipeline_covariance_over_more_iterations_than_slots(sw, n, kernel):
+    """The native pipeline paces itself on the progress flag once it has issued more launches than
+    it has buffer slots, and the covariance pass over iteration i rides along in launch i + 1 (quad
+    and row kernels) or runs as its own launch (lane kernel); the last one is flushed on demand.
+    Whatever the route, the accumulated covariance is np.cov over every recorded state."""
+    H, N, iters = 40, 5, 2 * sw.kernels.ArsPipeline().slots + 3
+    ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("Test", V1=False, n_iter=iters, H=H, N=N, b=N, alpha=0.0075, nu=0.05,
+                     safe=False, threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=11, record_trajectories=True, rollout_kernel=kernel)
+    for it in range(iters):
+        agent.runOneIteration()
+        if it == 3:       # reading it mid-way flushes the pass that is still owed, exactly once
+            mid = agent.covariance
+            states = np.asarray(agent.database.trajectories).reshape(-1, 2 * n + 2)
+            assert np.allclose(mid, np.cov(states.T), rtol=1e-9, atol=1e-12)
+    states = np.asarray(agent.database.trajectories).reshape(-1, 2 * n + 2)
+    assert states.shape[0] == iters * 2 * N * H
+    cov = agent.covariance
+    ref = np.cov(states.T)
+    assert np.allclose(cov, ref, rtol=1e-9, atol=1e-12), np.abs(cov - ref).max()
+    assert np.allclose(agent.covariance, cov)      # idempotent: nothing is added twice
+
+
 def test_top_b_variant_matches_safe_ars_semantics(sw):
     """safe_ars/ars.py:48-65, :95-96: only the best b directions enter sigma_R and the step."""
     from oracle.ars_oracle import ArsOracle
