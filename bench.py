@@ -64,10 +64,10 @@ def parse():
 def pmc_traffic(kernel, n, directions, H):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None when
     the measured workload is not the one being benchmarked."""
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_j_pmc_traffic.json")
     if not os.path.exists(path) or (n, directions, H) != (3, 512, 1000):
         return None
-    return json.load(open(path)).get(kernel, {}).get("traffic_bytes")
+    return json.load(open(path)).get(kernel, {})
 
 
 def issue_bound(n, H, kern_ms):
@@ -241,6 +241,7 @@ def main():
         alg_bytes = local_steps * 8 * d + 2 * agent.n_local * (8 * (n - 1) * d + 12)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         flops_per_step = {3: 330.0, 6: 1100.0}.get(n, 40.0 * n * n)  # fp64 flop count, DESIGN.md
+        traffic = pmc_traffic("rollout_quad3_kernel<true,true,true>", n, args.directions, H)
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -255,8 +256,8 @@ def main():
                                       "1 all-gather/iteration"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic("rollout_quad3_kernel<true,true,true>", n,
-                                                args.directions, H),
+                         "traffic": (traffic or {}).get("traffic_bytes"),
+                         "traffic_breakdown": (traffic or {}).get("breakdown"),
                          "algorithmic_bytes": alg_bytes,
                          "kernel": ("rollout_quad3_kernel<true,true,true>" if n == 3
                                     else f"rollout_row_kernel<{n},true,true,true>" if n >= 4
@@ -264,7 +265,10 @@ def main():
                          "kernel_ms": kern_ms,
                          "note": "the fused rollout is fp64-VALU-latency bound by construction "
                                  "(state, policy and sums stay in registers); HBM is the "
-                                 "contract's roofline, see DESIGN.md and aux.step_only",
+                                 "contract's roofline, see DESIGN.md and aux.step_only; the launch "
+                                 "also carries the covariance pass over the previous iteration's "
+                                 "trajectories (traffic_breakdown), achieved counts the rollouts' "
+                                 "bytes only",
                          "fp64_tflops": local_steps * flops_per_step / (kern_ms * 1e-3) / 1e12,
                          "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                          "issue_bound": issue_bound(n, H, kern_ms)},
