@@ -400,7 +400,7 @@ __device__ __forceinline__ void moments_pass(int64_t n_roll, const double *__res
             const double *tp = traj + (int64_t)t * D * n_roll + r;
             double x[D];
 #pragma unroll
-            for (int j = (J0 == 0 ? 0 : J0); j < D; ++j) {   // later passes need columns >= J0 only
+            for (int j = J0; j < D; ++j) {   // later passes need columns >= J0 only
                 const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
                 x[j] = tp[(int64_t)j * n_roll] - c;
             }
