@@ -1486,7 +1486,8 @@ struct sw_ars_pipeline {
     bool h2d_valid[SW_PIPELINE_SLOTS] = {};
     uint32_t *flag_host = nullptr, *flag_dev = nullptr;   // progress flag (pinned, mapped)
     uint32_t launches = 0;                                 // rollout launches issued so far
-    hipStream_t last_main = nullptr;
+    hipStream_t last_main = nullptr;                       // the stream of the launches so far ...
+    bool main_seen = false;                                // ... (may be the null stream)
     int timing = 0;                                        // 0 off, k: time every k-th launch
     int64_t timing_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // around the sampled rollout launches
@@ -1559,7 +1560,7 @@ void sw_ars_pipeline_destroy(sw_ars_pipeline *pl)
 {
     if (!pl) return;
     if (pl->copy) (void)hipStreamSynchronize(pl->copy);
-    if (pl->last_main) (void)hipStreamSynchronize(pl->last_main);   // kernels still write the flag
+    if (pl->main_seen) (void)hipStreamSynchronize(pl->last_main);   // kernels still write the flag
     for (auto &e : pl->timed) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -1587,7 +1588,7 @@ int sw_ars_pipeline_host_slot_wait(sw_ars_pipeline *pl, int slot)
 int sw_ars_pipeline_sync_cov(sw_ars_pipeline *pl)
 {
     if (!pl) return SW_ERR_NULL;
-    if (!pl->last_main && !pl->cov_traj) return SW_OK;
+    if (!pl->main_seen) return SW_OK;
     const int rc = flush_owed_cov(pl, pl->last_main);
     if (rc) return rc;
     return hipStreamSynchronize(pl->last_main) == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
@@ -1636,11 +1637,12 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
     if (slot < 0 || slot >= SW_PIPELINE_SLOTS || n_dir_total < dir_begin + n_dir) return SW_ERR_SIZE;
     if (cov_acc && !traj && n_dir > 0) return SW_ERR_NULL;
     hipStream_t main = (hipStream_t)stream;
-    if (pl->last_main && pl->last_main != main) {
+    if (pl->main_seen && pl->last_main != main) {
         // the progress flag orders work on ONE stream; a new stream starts from a clean slate
         if (hipStreamSynchronize(pl->last_main) != hipSuccess) return SW_ERR_LAUNCH;
     }
     pl->last_main = main;
+    pl->main_seen = true;
     const size_t bytes = (size_t)n_dir_total * (size_t)((p->n - 1) * (2 * p->n + 2)) * sizeof(double);
     // Launch k reuses the buffers of launch k - SLOTS: its device deltas were last read by update
     // k - SLOTS (done once launch k - SLOTS + 1 has started) and its trajectories by the

@@ -313,6 +313,29 @@ def test_pipeline_covariance_over_more_iterations_than_slots(sw, n, kernel):
     assert np.allclose(agent.covariance, cov)      # idempotent: nothing is added twice
 
 
+def test_pipeline_follows_the_callers_stream(sw):
+    """The pipeline enqueues on torch's current stream; switching streams mid-training (null
+    stream -> a side stream) must neither lose the covariance pass that is still owed nor
+    confuse the progress flag."""
+    n, H, N = 3, 30, 4
+    ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("Test", V1=False, n_iter=0, H=H, N=N, b=N, alpha=0.0075, nu=0.05,
+                     safe=False, threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=3, record_trajectories=True)
+    for _ in range(3):
+        agent.runOneIteration()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            agent.runOneIteration()
+        cov = agent.covariance
+    side.synchronize()
+    states = np.asarray(agent.database.trajectories).reshape(-1, 2 * n + 2)
+    assert states.shape[0] == 9 * 2 * N * H
+    assert np.allclose(cov, np.cov(states.T), rtol=1e-9, atol=1e-12)
+
+
 def test_top_b_variant_matches_safe_ars_semantics(sw):
     """safe_ars/ars.py:48-65, :95-96: only the best b directions enter sigma_R and the step."""
     from oracle.ars_oracle import ArsOracle
