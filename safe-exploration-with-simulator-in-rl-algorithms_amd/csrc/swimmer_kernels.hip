@@ -516,6 +516,62 @@ __device__ __forceinline__ void side_flag(const SideJob &sj)
         __hip_atomic_store(sj.flag, sj.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// This lane's pre-combined policy row V_i = c12 (W_{i-1} - W_i), W = (P +- nu delta) diag(inv_std)
+// (ars_agent.py:141-142, environment.py:32-34; u_{-1} = u_{n-1} = 0: free ends), and
+// nbias = -V_i . mean.  cols[j]: the observation column of entry j (the quad kernel keeps its
+// row in rotated order).  Branch-free on purpose: every lane loads both neighbouring rows with a
+// clamped row index and SELECTS afterwards, so all 4 D + 2 D loads are in flight together and the
+// launch pays one memory latency instead of ~40 serial ones (measured: the prologue was most of
+// the ~6 us fixed cost of a rollout launch).
+template <int D, int M, bool ARS>
+__device__ __forceinline__ void load_policy_row(const double *__restrict__ pl,
+                                                const double *__restrict__ dl, double sgn, double nu,
+                                                const double *__restrict__ mean,
+                                                const double *__restrict__ inv_std, double c12,
+                                                int seg, const int (&cols)[D], double (&V)[D],
+                                                double &nbias)
+{
+    const int a_up = (seg >= 1) ? seg - 1 : 0, a_dn = (seg <= M - 1) ? seg : M - 1;
+    double pu[D], pd[D], du[D], dd[D], is[D], mn[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        pu[j] = pl[a_up * D + cols[j]];
+        pd[j] = pl[a_dn * D + cols[j]];
+    }
+    if (ARS) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            du[j] = dl[a_up * D + cols[j]];
+            dd[j] = dl[a_dn * D + cols[j]];
+        }
+    }
+    if (inv_std) {   // uniform
+#pragma unroll
+        for (int j = 0; j < D; ++j) is[j] = inv_std[cols[j]];
+    }
+    if (mean) {      // uniform
+#pragma unroll
+        for (int j = 0; j < D; ++j) mn[j] = mean[cols[j]];
+    }
+    nbias = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double wu = pu[j], wd = pd[j];
+        if (ARS) {   // ars_agent.py:141-142
+            wu = __dadd_rn(wu, sgn * __dmul_rn(nu, du[j]));
+            wd = __dadd_rn(wd, sgn * __dmul_rn(nu, dd[j]));
+        }
+        if (inv_std) {   // environment.py:32-33
+            wu = __dmul_rn(wu, is[j]);
+            wd = __dmul_rn(wd, is[j]);
+        }
+        const double up = (seg >= 1) ? wu : 0.0;
+        const double dn = (seg <= M - 1) ? wd : 0.0;
+        V[j] = c12 * (up - dn);
+        if (mean) nbias = __builtin_fma(-V[j], mn[j], nbias);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // n = 3, one segment per lane (swimmer_quad3.h): 16 rollouts per 64-thread workgroup.
 // TRAJ / MOM are compile-time so the hot loop carries no per-step uniform branches.
@@ -556,25 +612,10 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
     // this lane's rotated order [Gdx, Gdy, th_i, thd_i, th_i1, thd_i1, th_i2, thd_i2]
     const int seg1 = (seg + 1) % 3, seg2 = (seg + 2) % 3;
     const int cols[D] = {0, 1, cth, cthd, 2 + 2 * seg1, 3 + 2 * seg1, 2 + 2 * seg2, 3 + 2 * seg2};
-    double V[D], nbias = 0.0;   // nbias = -V . mean: tq = V . (obs - mean) without per-step subtractions
-    {
-        const double *pl = ARS ? policies : policies + r * (M * D);
-        const double *dl = ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr;
-        const double sgn = (r & 1) ? -1.0 : 1.0;
-        auto entry = [&](int a, int col) {
-            double w = pl[a * D + col];
-            if (ARS) w = __dadd_rn(w, sgn * __dmul_rn(nu, dl[a * D + col]));   // ars_agent.py:141-142
-            if (inv_std) w = __dmul_rn(w, inv_std[col]);                       // environment.py:32-33
-            return w;
-        };
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const double up = (seg >= 1) ? entry(seg - 1, cols[j]) : 0.0;
-            const double dn = (seg <= M - 1) ? entry(seg, cols[j]) : 0.0;
-            V[j] = C.c12 * (up - dn);
-            if (mean) nbias = __builtin_fma(-V[j], mean[cols[j]], nbias);
-        }
-    }
+    double V[D], nbias;   // nbias = -V . mean: tq = V . (obs - mean) without per-step subtractions
+    load_policy_row<D, M, ARS>(ARS ? policies : policies + r * (M * D),
+                               ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr,
+                               (r & 1) ? -1.0 : 1.0, nu, mean, inv_std, C.c12, seg, cols, V, nbias);
 
     // ---- start state ----
     double gdx = 0.0, gdy = 0.0, th = kHalfPi, thd = 0.0;
@@ -745,24 +786,14 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
 
     // ---- this lane's policy row: V_i = c12 (W_{i-1} - W_i), W = (P +- nu delta) diag(inv_std)
     // (ars_agent.py:141-142, environment.py:32-34); u_{-1} = u_{n-1} = 0 (free ends)
-    double V[D], nbias = 0.0;   // nbias = -V . mean: tq = V . (obs - mean) without per-step subtractions
+    double V[D], nbias;   // nbias = -V . mean: tq = V . (obs - mean) without per-step subtractions
     {
-        const double *pl = ARS ? policies : policies + r * (M * D);
-        const double *dl = ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr;
-        const double sgn = (r & 1) ? -1.0 : 1.0;
-        auto entry = [&](int a, int col) {
-            double w = pl[a * D + col];
-            if (ARS) w = __dadd_rn(w, sgn * __dmul_rn(nu, dl[a * D + col]));
-            if (inv_std) w = __dmul_rn(w, inv_std[col]);
-            return w;
-        };
+        int cols[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const double up = (seg >= 1) ? entry(seg - 1, j) : 0.0;
-            const double dn = (seg <= M - 1) ? entry(seg, j) : 0.0;
-            V[j] = C.c12 * (up - dn);
-            if (mean) nbias = __builtin_fma(-V[j], mean[j], nbias);
-        }
+        for (int j = 0; j < D; ++j) cols[j] = j;   // canonical order
+        load_policy_row<D, M, ARS>(ARS ? policies : policies + r * (M * D),
+                                   ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr,
+                                   (r & 1) ? -1.0 : 1.0, nu, mean, inv_std, C.c12, seg, cols, V, nbias);
     }
 
     // ---- start state ----
@@ -897,17 +928,28 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
 }
 
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum(double v, double *sh)
+// two sums with one pair of barriers (the update kernel is pure latency: every barrier counts)
+__device__ __forceinline__ void block_sum2(double &a, double &b, double (*sh2)[2])
 {
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, kWave);
+        b += __shfl_down(b, off, kWave);
+    }
     const int w = threadIdx.x / kWave, l = threadIdx.x % kWave;
     __syncthreads();
-    if (l == 0) sh[w] = v;
+    if (l == 0) {
+        sh2[w][0] = a;
+        sh2[w][1] = b;
+    }
     __syncthreads();
-    double t = 0.0;
-    for (int i = 0; i < kUpdBlock / kWave; ++i) t += sh[i];
-    return t;
+    double ta = 0.0, tb = 0.0;
+    for (int i = 0; i < kUpdBlock / kWave; ++i) {
+        ta += sh2[i][0];
+        tb += sh2[i][1];
+    }
+    a = ta;
+    b = tb;
 }
 
 // Where the update finds an iteration's results.  After the all-gather every rank's segment
@@ -960,7 +1002,7 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                   double *__restrict__ mean, double *__restrict__ inv_std,
                   double *__restrict__ sigma_out)
 {
-    __shared__ double sh[kUpdBlock / kWave];
+    __shared__ double sh2[kUpdBlock / kWave][2];
     __shared__ double rp_s[kUpdMaxDirs], rm_s[kUpdMaxDirs];   // r+ and r- of every direction
     __shared__ unsigned char flag[kUpdMaxDirs];
     const int e = blockIdx.x;
@@ -1007,8 +1049,7 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                 s += rplus(i) + rminus(i);
                 cnt += 2.0;
             }
-        s = block_sum(s, sh);
-        cnt = block_sum(cnt, sh);
+        block_sum2(s, cnt, sh2);
         const double mu = s / cnt;
         double v = 0.0, g = 0.0;
         if (in_lds) {
@@ -1031,8 +1072,7 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                     g = __builtin_fma(rp - rm, deltas[(int64_t)i * md + e], g);
                 }
         }
-        v = block_sum(v, sh);
-        g = block_sum(g, sh);
+        block_sum2(v, g, sh2);
         if (threadIdx.x == 0) {
             const double sigma = sqrt(v / cnt);
             const double grad = g / (b * sigma);            // ars_agent.py:128
@@ -1081,11 +1121,6 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         }
     }
 }
-
-// ------------------------------------------------------------------------------------
-// Full moments of traj[H][D][R].  Workgroup (bx, by): rollouts bx*256.., steps by*TCHUNK..;
-// every load is a coalesced row segment; partial sums are reduced over the workgroup and
-// added to acc with fp64 atomics (d + d(d+1)/2 + 1 atomics per workgroup).
 
 // ---- dispatch on the segment count -------------------------------------------------
 #define SW_DISPATCH_N(n, CALL)                 \
