@@ -589,12 +589,12 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         side_cov_tile<8, kRollBlock>(side);
         return;
     }
-    // This wave's speed IS the iteration time, so it must not share its SIMD's issue slots with
-    // the covariance workgroups of the same launch (or, multi-GPU, the collective's waves):
-    // touching the last VGPR and the last AGPR makes the kernel allocate the SIMD's whole
-    // register file (512 per lane), i.e. exactly one wave of this kernel fits on a SIMD and
-    // nothing else does.  (s_setprio alone does not help: a 4-cycle f64 op of the other wave is
-    // not pre-empted.  Measured: 4.5-7.6 us per iteration.)
+    // This wave's speed IS the iteration time, so it should not share its SIMD's issue slots with
+    // anything else (the covariance workgroups of the same launch; multi-GPU, the collective's
+    // waves): touching the last VGPR and the last AGPR makes the kernel allocate the SIMD's whole
+    // register file (512 per lane), i.e. exactly one wave fits on a SIMD, and s_setprio puts it
+    // first in line.  A guard, not a measured win: on one GPU the A/B is neutral (0.2928 vs
+    // 0.2929 ms per iteration), the covariance workgroups cost the rollouts ~1 us either way.
     asm volatile("" ::: "v255", "a255");
     __builtin_amdgcn_s_setprio(3);
     constexpr int D = 8, M = 2;
