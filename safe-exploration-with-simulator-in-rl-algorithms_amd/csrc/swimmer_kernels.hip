@@ -589,13 +589,11 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         side_cov_tile<8, kRollBlock>(side);
         return;
     }
-    // This wave's speed IS the iteration time, so it should not share its SIMD's issue slots with
-    // anything else (the covariance workgroups of the same launch; multi-GPU, the collective's
-    // waves): touching the last VGPR and the last AGPR makes the kernel allocate the SIMD's whole
-    // register file (512 per lane), i.e. exactly one wave fits on a SIMD, and s_setprio puts it
-    // first in line.  A guard, not a measured win: on one GPU the A/B is neutral (0.2928 vs
-    // 0.2929 ms per iteration), the covariance workgroups cost the rollouts ~1 us either way.
-    asm volatile("" ::: "v255", "a255");
+    // This wave's speed IS the iteration time: first in line at the instruction arbiter when a
+    // covariance workgroup of the same launch (or, multi-GPU, a collective's wave) lands on its
+    // SIMD.  (Reserving the SIMD outright -- allocating all 512 registers by touching v255 / a255
+    // -- measured neutral on one GPU and would serialise the covariance workgroups behind the
+    // rollouts once a batch fills the chip, so it is not done.)
     __builtin_amdgcn_s_setprio(3);
     constexpr int D = 8, M = 2;
     const int lane = threadIdx.x;
@@ -771,8 +769,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         side_cov_tile<2 * N + 2, kRowBlock>(side);
         return;
     }
-    asm volatile("" ::: "v255", "a255");   // one wave per SIMD, as in the quad kernel
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);   // as in the quad kernel
     constexpr int D = 2 * N + 2, M = N - 1;
     const int tid = threadIdx.x;
     const int q = tid & 15;                        // lane inside the row

@@ -288,13 +288,16 @@ def test_ars_training_and_store(sw, golden, tmp_path):
     assert z["policies"].shape == (5 * 6, 2, 8) and z["trajectories"].shape == (5 * 6, 60, 8)
 
 
-@pytest.mark.parametrize("n,kernel", [(3, "auto"), (5, "auto"), (3, "lane"), (2, "auto")])
-def test_pipeline_covariance_over_more_iterations_than_slots(sw, n, kernel):
+@pytest.mark.parametrize("n,kernel,N,H", [(3, "auto", 5, 40), (5, "auto", 5, 40), (3, "lane", 5, 40),
+                                          (2, "auto", 5, 40),
+                                          (3, "auto", 8192, 5),     # 1024 waves: the quad kernel fills the chip
+                                          (3, "auto", 8200, 5)])    # just beyond: the lane kernel takes over
+def test_pipeline_covariance_over_more_iterations_than_slots(sw, n, kernel, N, H):
     """The native pipeline paces itself on the progress flag once it has issued more launches than
     it has buffer slots, and the covariance pass over iteration i rides along in launch i + 1 (quad
     and row kernels) or runs as its own launch (lane kernel); the last one is flushed on demand.
     Whatever the route, the accumulated covariance is np.cov over every recorded state."""
-    H, N, iters = 40, 5, 2 * sw.kernels.ArsPipeline().slots + 3
+    iters = 2 * sw.kernels.ArsPipeline().slots + 3 if N < 100 else sw.kernels.ArsPipeline().slots + 2
     ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
     ap = sw.ARSParam("Test", V1=False, n_iter=iters, H=H, N=N, b=N, alpha=0.0075, nu=0.05,
                      safe=False, threshold=0, initial_w="Zero")
