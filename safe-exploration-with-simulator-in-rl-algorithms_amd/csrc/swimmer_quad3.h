@@ -5,15 +5,16 @@
 // 1024 SIMDs x 64 lanes.  With one rollout per lane (rollout_kernel) a batch of 1024
 // rollouts occupies 16 SIMDs and its speed is the length of one lane's instruction stream
 // (~310 instructions per step, one instruction per ~4.4 cycles for a lone wave,
-// scripts/ubench).  Spreading a rollout over the lanes of a quad cuts that stream to ~170
+// scripts/ubench).  Spreading a rollout over the lanes of a quad cuts that stream to 145
 // instructions per step at 4x the (idle anyway) SIMD count:
 //
 //   lane q = 0,1,2 of a quad owns segment q: its angle, angular velocity, sin/cos, its row
 //   of the 3x3 joint-acceleration system and its V2 moment sums.  The joint torques are never
 //   formed: lane i only needs u_{i-1} - u_i, which is linear in the observation, so it holds
 //   the pre-combined policy row V_i = 12/(m l^2) (W_{i-1} - W_i) (columns in its rotated
-//   order) and evaluates one 8-term dot product on (observation - mean); lane 3 mirrors lane 0 bit for bit (same inputs, same permutation sources),
-//   so whatever it stores duplicates lane 0's stores.
+//   order) and evaluates one 8-term dot product on the observation (the mean enters as one
+//   constant per rollout); lane 3 mirrors lane 0 bit for bit (same inputs, same permutation
+//   sources), so whatever it stores duplicates lane 0's stores.
 //   Neighbour data moves with DPP quad_perm moves (no LDS, no memory, two 32-bit moves per
 //   double): next1 = segment (q+1)%3, next2 = segment (q+2)%3.
 //   Every lane solves the SAME symmetric 3x3 system in its own rotated order
@@ -23,8 +24,12 @@
 //   Gdot is replicated per lane and re-synchronised from lane 0 after every step, so the
 //   state of a rollout is well defined: Gdot from lane 0, (theta_i, thetadot_i) from lane i.
 //
+//   The angle-only part of step t+1 (sin/cos, their exchange, pairwise cos/sin of differences)
+//   is evaluated beside step t's solve: theta_{t+1} needs thetadot_t only (Quad3Geo).
+//
 // Same equations as swimmer_device.h (see the derivation there); the per-step arithmetic
-// differs from rollout_kernel only in summation order (<= a few ulp per step).
+// differs from rollout_kernel in summation order and in the reciprocal's last Newton step
+// (2e-15 relative on thetaddot, see rcp_f64_1n).
 #pragma once
 
 #include "swimmer_device.h"
