@@ -38,3 +38,45 @@ def test_plain_c_client(tmp_path):
     ret, _ = oracle.rollout(p, 100, policy, state0=state)
     assert abs(float(lines["rollout"][0]) - ret) <= 1e-10
     assert lines["bad_n"] == ["2", "null_ptr", "1"]
+
+
+@pytest.mark.gpu
+def test_plain_c_ars_pipeline(tmp_path):
+    """tests/c/ars_client.c: the native ARS pipeline driven from C for more iterations than it has
+    buffer slots, against the oracle of the reference's ARS V2 loop on the same perturbations."""
+    from oracle.ars_oracle import ArsOracle
+    gcc = shutil.which("gcc")
+    exe = str(tmp_path / "ars_client")
+    csrc = os.path.join(PKG, "csrc")
+    rocm = "/opt/rocm"
+    subprocess.check_call([gcc, "-std=c11", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "ars_client.c"),
+                           "-L", csrc, "-lswimmer_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", exe])
+    iters, N, H, seed, n = 7, 6, 200, 21, 3
+    m, d = n - 1, 2 * n + 2
+    rng = np.random.RandomState(seed)    # the draws ArsOracle(seed) makes, in its order
+    deltas = np.stack([np.stack([2 * rng.rand(m, d) - 1 for _ in range(N)]) for _ in range(iters)])
+    deltas.tofile(tmp_path / "deltas.bin")
+    out = subprocess.run([exe, str(tmp_path / "deltas.bin"), str(iters), str(N), str(H),
+                          str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["iterations", str(iters), "status", "0"]
+    res = np.fromfile(tmp_path / "out.bin")
+    md, ncov = m * d, 1 + d + d * d
+    policy, mean, inv_std = res[:md].reshape(m, d), res[md:md + d], res[md + d:md + 2 * d]
+    acc, rets = res[md + 2 * d:md + 2 * d + ncov], res[md + 2 * d + ncov:]
+    ref = ArsOracle(n, 0.8, 1.2, 10.2, 1e-3, H, N, N, 0.0075, 0.01, False, seed)
+    for _ in range(iters):
+        ref_rets = ref.iteration()
+    assert np.abs(rets - np.array(ref_rets)).max() <= 1e-9
+    assert np.abs(policy - ref.policy).max() <= 1e-9
+    assert np.abs(mean - ref.mean).max() <= 1e-10
+    ref_inv = np.diag(ref.covariance) ** -0.5
+    rel = np.abs(inv_std / ref_inv - 1.0).max()
+    print(f"inv_std: max relative deviation {rel:.3e}")
+    assert rel <= 1e-7    # one-pass pivoted sums on the device vs np.cov's two passes: observed 4e-9
+    cnt, s1, s2 = acc[0], acc[1:1 + d], acc[1 + d:].reshape(d, d)
+    assert cnt == iters * 2 * N * H
+    cov = (s2 - np.outer(s1, s1) / cnt) / (cnt - 1.0)
+    assert np.allclose(cov, ref.covariance, rtol=1e-8, atol=1e-12)
