@@ -187,6 +187,13 @@ def main():
     import swimmer_amd as sw
     sw._lib.load()
 
+    # Everything runs on a stream of its own, not on the null stream: work on the null stream is
+    # implicitly ordered against every other blocking stream of the process, and once a
+    # ProcessGroupNCCL exists that costs the iteration 13 us of device-side waits (measured with
+    # one rank: 0.3031 vs 0.2903 ms; scripts/collective_overhead.py).  The library itself
+    # follows the caller's current stream.
+    torch.cuda.set_stream(torch.cuda.Stream(device))
+
     n, H = args.segments, args.horizon
     N = args.directions * world
     ep = sw.EnvParam("LeonSwimmer-Bench", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)

@@ -16,6 +16,11 @@ drawn as 2*rand(m, d)-1, ars_agent.py:95,137).  What differs is where the work h
 
 The safe-exploration gate (ars_agent.py:144-157) is sequential by construction and is not
 part of this path: agent_param.safe=True raises NotImplementedError.
+
+Streams: every launch goes to torch's CURRENT stream.  With a NCCL process group alive, work on
+the null (default) stream is implicitly ordered against the group's streams, which costs an
+iteration ~13 us of device-side waits (measured); run distributed training under a stream of
+its own, e.g. torch.cuda.set_stream(torch.cuda.Stream()), as bench.py does.
 """
 import os
 
