@@ -42,7 +42,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 # of the hot loop incl. trajectory stores + moments, scripts/isa_loop_stats.py) and the measured
 # issue interval of a lone wave (profiles/r01_ubench_issue_cost.log: 1.92-2.13 ns per
 # independent instruction of any kind): what actually bounds the latency-bound rollout.
-ROLLOUT_INSTR_PER_STEP = {3: 145, 6: 252}
+ROLLOUT_INSTR_PER_STEP = {3: 145, 6: 256}
 TIME_EVERY = 8
 LONE_WAVE_NS_PER_INSTR = 1.90   # lower edge of the measured per-instruction intervals (v_mov_b64 1.92, f64 + SALU 1.98, f64 FMA 2.13; DPP-heavy mixes come in slightly under)
 

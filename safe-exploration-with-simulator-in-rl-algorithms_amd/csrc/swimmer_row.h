@@ -12,9 +12,10 @@
 //   lane i < N of a row owns segment i: theta_i, thetadot_i, sin/cos, row i of Q thdd = r.
 //   Sums over segments (policy dot product, normal velocity, barycentre acceleration, right-hand
 //   side) are chains of fused broadcast-FMAs reading the other lanes' registers directly.
-//   The n x n SPD system is solved COOPERATIVELY: unpivoted Gaussian elimination where step j
-//   broadcasts pivot row j out of lane j's registers and every lane below updates its own row
-//   (one fused instruction per entry), then a broadcast back-substitution; lane i ends with
+//   The n x n SPD system is solved COOPERATIVELY: unpivoted, division-free Gaussian elimination
+//   where step j broadcasts pivot row j out of lane j's registers and every lane below updates
+//   its own row (a multiply and a fused broadcast-FMA per entry, no reciprocal on the pivot
+//   chain), then one reciprocal per lane and a broadcast back-substitution; lane i ends with
 //   thdd_i.
 //   The joint torques never exist as such: lane i needs only u_{i-1} - u_i, which is linear in
 //   the observation, so it holds the pre-combined policy row V_i = c12 (W_{i-1} - W_i) and
@@ -92,35 +93,24 @@ struct RowGather<N, N> {
 };
 
 // Cooperative solve of Q x = b: lane i holds row i (a[0..N-1]) and b_i; ends with x_i on lane i.
-// rq: lane i's 1 / (pivot i) -- its sign doubles as the positive-definiteness check.
-// Step J: the compiler's own DPP move broadcasts the pivot (it manages that hazard itself),
-// the reciprocal chain follows, then ONE asm block updates the rows below with fused
-// broadcast-FMAs (RowFused<N>::eliminate<J>, which also documents the hazard distances).
+// Division-free Gaussian elimination: step J broadcasts the pivot Q_JJ out of lane J (the
+// compiler's own DPP move, it manages that hazard itself) and every lane below replaces its row by
+// Q_JJ * row_i - Q_iJ * row_J in ONE asm block of multiplies and fused broadcast-FMAs
+// (RowFused<N>::eliminate<J>, which also documents the hazard distances).  Rows are scaled by
+// the pivots above them (products of O(1) numbers for these chains), which the back-substitution
+// undoes with one reciprocal per lane.
 template <int N, int J = 0>
 struct RowEliminate {
-    static __device__ __forceinline__ void run(const RowLane<N> &L, double (&a)[N], double &b, double &rq)
+    static __device__ __forceinline__ void run(const RowLane<N> &L, double (&a)[N], double &b)
     {
-        // 1 / pivot: hardware estimate r0 + one Newton step (rcp_f64_1n), spelled out so that the
-        // multiplier nf = -Q_iJ / Q_JJ (lanes i > J, else 0) is TWO dependent operations behind r0
-        // instead of three: nf = (na r0) (1 + e) instead of na (r0 (1 + e)).  This chain
-        // (broadcast -> rcp -> e, nf0 -> nf -> row update -> next broadcast) is the serial
-        // backbone of the step.
-        const double piv = row_bcast<J>(a[J]);
-        const double r0 = __builtin_amdgcn_rcp(piv);
-        const double e = __builtin_fma(-piv, r0, 1.0);
         if constexpr (J < N - 1) {
-            const double nf0 = (L.nbelow[J] * a[J]) * r0;
-            const double nf = __builtin_fma(nf0, e, nf0);
-            RowFused<N>::template eliminate<J>(a, b, nf);
+            const double piv = row_bcast<J>(a[J]);
+            const double sel = __builtin_fma(L.nbelow[J], 1.0 - piv, 1.0);   // pivot on lanes i > J, else 1
+            const double nm = L.nbelow[J] * a[J];                            // -Q_iJ on lanes i > J, else 0
+            RowFused<N>::template eliminate<J>(a, b, sel, nm);
+            RowEliminate<N, J + 1>::run(L, a, b);
         }
-        const double rp = __builtin_fma(r0, e, r0);
-        rq = __builtin_fma(L.one[J], rp, rq);          // lane J keeps 1 / Q_JJ
-        RowEliminate<N, J + 1>::run(L, a, b, rq);
     }
-};
-template <int N>
-struct RowEliminate<N, N> {
-    static __device__ __forceinline__ void run(const RowLane<N> &, double (&)[N], double &, double &) {}
 };
 
 // One explicit-Euler step.  gdx, gdy: replicated (bit-identical on all lanes); th, thd: own
@@ -160,11 +150,15 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
     double sx = 0.0, sy = 0.0;
     RowFused<N>::sums(sx, sy, r, g, sk, ck, ac);
     th = __builtin_fma(C.h, thd, th);                 // explicit Euler: the OLD thetadot
-    // everything the elimination reads by DPP is written before the first pivot's reciprocal
-    // chain starts
+    // everything the elimination reads by DPP is written before the first pivot is broadcast
     RowFused<N>::fence(a);
-    double rq = 0.0;
-    RowEliminate<N>::run(L, a, r, rq);
+    RowEliminate<N>::run(L, a, r);
+    // this lane's own (scaled) pivot and its reciprocal -- the sign doubles as the positive-
+    // definiteness check (the scale factors are pivots of the rows above, positive themselves)
+    double dg = L.one[0] * a[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) dg = __builtin_fma(L.one[k], a[k], dg);
+    const double rq = rcp_f64_1n(dg);
     // back-substitution on the scaled right-hand side (RowFused<N>::backsub)
     double tdd = r * rq;
     const double nu_top = (L.nabove[N - 1] * a[N - 1]) * rq;

@@ -91,36 +91,48 @@ def gen(n):
     s.append("    }\n\n")
     # ---- ordering point ----
     allrows = ", ".join(f'"+v"(a[{k}])' for k in range(n))
-    s.append(f"""    // No instruction: an ordering point.  Every a[k] is written before it and the first pivot's
-    // broadcast + reciprocal chain (>= 7 instructions) comes after it, so the DPP reads of
-    // eliminate<0> are never closer than that to the writes of the matrix row.
+    s.append(f"""    // No instruction: an ordering point.  Every a[k] is written before it; the first pivot's
+    // broadcast, the sel / nm arithmetic and the block's own multiplies (>= 4 + N instructions)
+    // come after it, so the DPP reads of eliminate<0> are never closer than that to the writes
+    // of the matrix row.
     static __device__ __forceinline__ void fence(double (&a)[{n}])
     {{
         asm volatile("" : {allrows});
     }}
 
 """)
-    # ---- elimination updates ----
-    s.append(f"""    // Elimination step J: rows below the pivot subtract (Q_iJ / Q_JJ) x pivot row J, which lives in
-    // lane J's registers: a[k] += [lane J].a[k] * nf, r += [lane J].r * nf   (nf = -Q_iJ / Q_JJ on
-    // lanes i > J, 0 elsewhere; lane J itself adds 0, so D == S0 is harmless).  DPP sources: written
-    // by the previous step's block, behind the >= 7 instructions of the pivot's reciprocal chain
-    // (which needs that block's a[J] and feeds nf).  Each block writes a[J+1] -- the next pivot,
-    // which the compiler's own DPP move reads next -- FIRST, >= 2 instructions before its end; the
-    // last block has only two instructions and pads with s_nop 0.
+    # ---- elimination step (division-free) ----
+    s.append(f"""    // Elimination step J, division-free: row_i <- sel * row_i + nm * [lane J].row   with
+    // sel = pivot Q_JJ on lanes i > J (1 elsewhere) and nm = -Q_iJ on lanes i > J (0 elsewhere; lane J
+    // itself multiplies by 1 and adds 0).  The rows span the same space as with the usual multiplier
+    // Q_iJ / Q_JJ, but no step needs 1 / pivot: the serial pivot chain carries no v_rcp_f64 (16 issue
+    // cycles each), every lane takes ONE reciprocal of its own scaled pivot after the last step.
+    // All multiplies first, then the fused broadcast-FMAs: no instruction waits on its neighbour.
+    // DPP sources a[k], r: written by the previous step's block, behind this step's pivot broadcast
+    // and the two instructions that form sel / nm (the first block sits behind `fence`).  a[J+1] --
+    // the next pivot, which the compiler's own DPP move reads next -- is written >= 2 instructions
+    // before the end (the two-entry block pads with s_nop 0).
     template <int J>
-    static __device__ __forceinline__ void eliminate(double (&a)[{n}], double &r, double nf)
+    static __device__ __forceinline__ void eliminate(double (&a)[{n}], double &r, double sel, double nm)
     {{
 """)
     for j in range(n - 1):
-        outs = [f"a[{k}]" for k in range(j + 1, n)] + ["r"]
-        nacc = len(outs)
-        lines = [fmac(i, i, nacc, j) for i in range(nacc)]
-        if j == n - 2:
+        ents = [f"a[{k}]" for k in range(j + 1, n)] + ["r"]
+        ne = len(ents)
+        # operands: outputs t0..t(ne-1) (early clobber), inputs e0..e(ne-1), sel, nm
+        lines = [f"v_mul_f64 %{i}, %{ne + i}, %{2 * ne}" for i in range(ne)]
+        lines += [f"v_fmac_f64_dpp %{i}, %{ne + i}, %{2 * ne + 1} " + DPP.format(k=j) for i in range(ne)]
+        if ne == 2:
             lines.append("s_nop 0")
         kw = "if" if j == 0 else "else if"
         s.append(f"        {kw} constexpr (J == {j}) {{\n")
-        s.append(asm_block(lines, outs, ["nf"], indent="            "))
+        s.append("            double " + ", ".join(f"t{i}" for i in range(ne)) + ";\n")
+        body = "\n".join(f'                "{l}\\n"' for l in lines)
+        o = ", ".join(f'"=&v"(t{i})' for i in range(ne))
+        i_ = ", ".join(f'"v"({x})' for x in ents + ["sel", "nm"])
+        s.append(f"            asm volatile(\n{body}\n                : {o}\n                : {i_});\n")
+        for i, e in enumerate(ents):
+            s.append(f"            {e} = t{i};\n")
         s.append("        }\n")
     s.append("    }\n\n")
     # ---- back-substitution ----
