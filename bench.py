@@ -6,8 +6,12 @@ sample N perturbations on the host (NumPy legacy RNG, like the reference), run t
 H-step rollouts in the fused HIP rollout kernel (trajectory capture + V2 moments on), gather
 returns (RCCL all-gather when --gpus > 1), update the policy and the running state
 statistics, and reduce the full state covariance from the recorded trajectories.
-Weak scaling: every GPU gets --directions (default 512) directions, so the whole job runs
-N = 512 * n_gpus directions (4 GPUs = the 2048-direction config).
+
+  --scaling weak   (default) every GPU gets --directions (512) directions: N = 512 * n_gpus
+                   (4 GPUs = the 2048-direction config); with more than one rank the line also
+                   carries aux.strong_2048_directions, the fixed-size problem on the same ranks
+  --scaling strong BASELINE configs[3] / [4] as stated: --total-directions (2048) directions in
+                   all, sharded over the ranks (add --segments 6 for configs[4])
 
 metric = env-steps/s over the whole job = 2 * N * H * steps / wall time of the timed region.
 
@@ -16,24 +20,23 @@ Prints ONE JSON line on rank 0 (contract in the task description) with two extra
                 duration of that launch, against the 8 TB/s HBM3E peak
   cpu_baseline  the C restatement of the reference (oracle/, OpenMP over the host cores) on
                 a bounded sample of the same workload
-and an "aux" object with the physics-step-only kernel (configs[1]) at 8192 envs and at a
-bandwidth-bound batch.
+and an "aux" object: the physics-step-only kernel (configs[1]) at 8192 envs and at a
+bandwidth-bound batch, the per-GPU shards of configs[3] / [4], the saturated rollout regime.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: spawns the N ranks itself)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (also fine)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MEASURED_COPY_PEAK_GBPS = 5690.0   # scripts/ubench/stream_copy on the box (profiles/r01_g_stream_copy.log)
@@ -43,38 +46,119 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 # issue interval of a lone wave (profiles/r01_ubench_issue_cost.log: 1.92-2.13 ns per
 # independent instruction of any kind): what actually bounds the latency-bound rollout.
 ROLLOUT_INSTR_PER_STEP = {3: 145, 6: 256}
-TIME_EVERY = 8
+TIME_EVERY = 4                  # HIP events around every 4th rollout launch of the timed region
+POSTPASS_LAUNCHES = 16          # + every launch of an untimed post-pass
 LONE_WAVE_NS_PER_INSTR = 1.90   # lower edge of the measured per-instruction intervals (v_mov_b64 1.92, f64 + SALU 1.98, f64 FMA 2.13; DPP-heavy mixes come in slightly under)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--directions", type=int, default=512, help="ARS directions per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--directions", type=int, default=512, help="weak: ARS directions per GPU")
+    ap.add_argument("--total-directions", type=int, default=2048,
+                    help="strong: ARS directions of the whole job (BASELINE configs[3]/[4])")
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--segments", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-aux", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------
+# Launcher: `python bench.py --gpus N` without a torch.distributed.run wrapper.  The parent has
+# made no GPU call (importing torch initialises nothing); it only spawns one child per rank with
+# the usual rendezvous variables, relays rank 0's line and propagates failures.
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_environment(rank, world, port, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    return env
+
+
+def launch_ranks(world, argv, script=None, timeout=None):
+    """Spawn `world` rank processes of this script, wait, print rank 0's stdout.  Returns the
+    exit code: 0 only if every rank exited 0.  When one rank fails the others (who would wait
+    for it in a collective forever) are terminated by PID."""
+    script = script or os.path.abspath(__file__)
+    timeout = float(os.environ.get("SWIMMER_BENCH_LAUNCH_TIMEOUT", "1500")) if timeout is None else timeout
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(
+            [sys.executable, script] + list(argv), env=rank_environment(r, world, port),
+            stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = failed[0] if failed[0] > 0 else 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            print(f"bench launcher: ranks still running after {timeout:.0f} s", file=sys.stderr)
+            rc = 124
+            break
+        time.sleep(0.05)
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(5)
+    for ln in (out0[0].splitlines() if out0 and out0[0] else []):
+        # rank 0's result line goes to stdout; whatever the communication libraries printed to
+        # its stdout ("[Gloo] Rank 0 is connected ...") goes to stderr
+        print(ln, file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr, flush=True)
+    if rc:
+        print(f"bench launcher: a rank failed (exit code {rc}); codes = "
+              f"{[p.poll() for p in procs]}", file=sys.stderr)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------
 def pmc_traffic(kernel, n, directions, H):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None when
     the measured workload is not the one being benchmarked."""
-    path = os.path.join(ROOT, "profiles", "r01_j_pmc_traffic.json")
-    if not os.path.exists(path) or (n, directions, H) != (3, 512, 1000):
+    if (n, directions, H) != (3, 512, 1000):
         return None
-    return json.load(open(path)).get(kernel, {})
+    for name in ("r02_pmc_traffic.json", "r01_j_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            t = json.load(open(path)).get(kernel)
+            if t:
+                return dict(t, source="profiles/" + name)
+    return None
 
 
 def issue_bound(n, H, kern_ms):
     """The rollout kernel's real ceiling: every wave runs alone on its SIMD and can issue one
     instruction per ~2.1 ns, so a rollout batch cannot finish faster than
     H x instructions-per-step x that interval, whatever the batch size."""
-    if n not in ROLLOUT_INSTR_PER_STEP:
+    if n not in ROLLOUT_INSTR_PER_STEP or not kern_ms:
         return None
     floor_ms = H * ROLLOUT_INSTR_PER_STEP[n] * LONE_WAVE_NS_PER_INSTR * 1e-6
     return {"instructions_per_step": ROLLOUT_INSTR_PER_STEP[n],
@@ -82,9 +166,24 @@ def issue_bound(n, H, kern_ms):
             "floor_ms": floor_ms, "frac": floor_ms / kern_ms}
 
 
+def rollout_kernel_name(n):
+    return ("rollout_quad3_kernel<true,true,true>" if n == 3
+            else f"rollout_row_kernel<{n},true,true,true>" if n >= 4
+            else f"rollout_kernel<{n},true,false>")
+
+
+def rollout_algorithmic_bytes(n, n_dir_local, H):
+    """Algorithmic HBM bytes of one rollout launch: every post-step state is materialised
+    (8 d bytes per env-step, as the reference does, ars/environment.py:53) + per rollout its
+    delta row (8 m d), return (8) and status (4)."""
+    d = 2 * n + 2
+    return 2 * n_dir_local * H * 8 * d + 2 * n_dir_local * (8 * (n - 1) * d + 12)
+
+
 def cpu_baseline(n, H, directions, seconds):
     """Time the oracle (C port of the reference step/rollout, OpenMP) on whole rollout
     batches of the benchmark's shape until `seconds` have elapsed."""
+    import numpy as np
     import oracle
     oracle.build()
     oracle.set_num_threads(oracle.cpu_share())
@@ -109,8 +208,9 @@ def cpu_baseline(n, H, directions, seconds):
                       f"oracle/swimmer_oracle.c with OpenMP, {dt:.1f} s"}
 
 
-def aux_step_only(sw, n, device):
+def aux_step_only(sw, torch, n, device):
     """Physics-step-only kernel (configs[1]): 8192 envs, and a bandwidth-bound batch."""
+    import numpy as np
     p = sw.SwParams.make(n)
     d, m = 2 * n + 2, n - 1
     out = {}
@@ -139,42 +239,129 @@ def aux_step_only(sw, n, device):
     return out
 
 
-def aux_more_directions(sw, n, H, device, directions=2048, iters=12):
-    """The same ARS iteration at configs[3]'s problem size (2048 directions = 4096 rollouts) on
-    ONE GPU: the rollout kernel is latency-bound, so the larger batch rides along almost free."""
-    ep = sw.EnvParam("LeonSwimmer-Bench", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
-    ap = sw.ARSParam("Bench", V1=False, n_iter=iters, H=H, N=directions, b=directions, alpha=0.0075,
-                     nu=0.01, safe=False, threshold=0, initial_w="Zero")
+def aux_rollout_saturated(sw, torch, device, n=3, n_roll=262144, H=1000, reps=3):
+    """Where the ROLLOUT path is HBM-bound: the lane-per-rollout kernel on a batch that fills the
+    chip (262 144 rollouts x H = 1000) with every post-step state captured, 16.8 GB of stores."""
+    import numpy as np
+    p = sw.SwParams.make(n, flags=sw._lib.FLAG_ROLLOUT_LANE)
+    d, m = 2 * n + 2, n - 1
+    rng = np.random.RandomState(1)
+    pol = torch.as_tensor(0.01 * (2 * rng.rand(4096, m, d) - 1), device=device).repeat(n_roll // 4096, 1, 1)
+    traj = torch.empty((H, d, n_roll), dtype=torch.float64, device=device)
+    rets = torch.empty(n_roll, dtype=torch.float64, device=device)
+    sw.kernels.rollout(p, H, pol, traj=traj, returns=rets)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sw.kernels.rollout(p, H, pol, traj=traj, returns=rets)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    byts = n_roll * H * 8 * d + n_roll * (8 * m * d + 8)
+    del traj
+    torch.cuda.empty_cache()
+    return {"kernel": f"rollout_kernel<{n},false,false> (one rollout per lane)",
+            "rollouts": n_roll, "horizon": H, "trajectory_capture": True, "ms": ms,
+            "env_steps_per_s": n_roll * H / (ms * 1e-3), "algorithmic_bytes": byts,
+            "achieved_GBps": byts / (ms * 1e-3) / 1e9,
+            "hbm_frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+
+class ArsLeg(object):
+    """One ARS V2 workload on this rank: agent + the timed loop + the kernel-timing post-pass."""
+
+    def __init__(self, sw, torch, n, H, N, device):
+        self.sw, self.torch, self.n, self.H, self.N = sw, torch, n, H, N
+        ep = sw.EnvParam("LeonSwimmer-Bench", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+        ap = sw.ARSParam("Bench", V1=False, n_iter=0, H=H, N=N, b=N, alpha=0.0075, nu=0.01,
+                         safe=False, threshold=0, initial_w="Zero")
+        self.agent = sw.ARSAgent(ep, ap, seed=0, device=device, full_covariance=True)
+
+    def run(self, warmup, steps, sync, time_every=TIME_EVERY, postpass=POSTPASS_LAUNCHES):
+        agent, torch = self.agent, self.torch
+        for _ in range(warmup):
+            agent.run_iteration_async(want_returns=False)
+        sync()
+        # HIP events on the launch stream around every k-th rollout launch of the timed region:
+        # a timed launch costs ~10 us of pipeline bubbles (measured), so timing all of them
+        # would slow the very loop being measured by 3 %
+        agent._pipe.timing(time_every)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            agent.run_iteration_async(want_returns=False)
+        sync()
+        dt = time.perf_counter() - t0
+        k_ms, k_n = agent._pipe.rollout_ms()
+        # post-pass outside the timed region: every launch timed, and (world > 1) the collective
+        res = {"seconds": dt, "kernel_ms_timed_region": k_ms, "kernel_samples_timed_region": k_n}
+        if postpass > 0 and agent.n_local > 0:
+            agent._pipe.timing(1)
+            agent.collective_timing(True)
+            for _ in range(postpass):
+                agent.run_iteration_async(want_returns=False)
+            sync()
+            p_ms, p_n = agent._pipe.rollout_ms()
+            res.update(kernel_ms_postpass=p_ms, kernel_samples_postpass=p_n,
+                       collective_us=agent.collective_us())
+            agent.collective_timing(False)
+            tot = k_ms * k_n + p_ms * p_n
+            res.update(kernel_ms=tot / (k_n + p_n), kernel_samples=k_n + p_n)
+        else:
+            res.update(kernel_ms=k_ms, kernel_samples=k_n)
+        agent._pipe.timing(0)
+        return res
+
+    def check(self, rank):
+        import numpy as np
+        bad = int((self.agent._status != 0).sum().item())
+        if bad or not np.isfinite(self.agent.policy).all():
+            raise SystemExit(f"rank {rank}: bench produced {bad} bad rollouts / non-finite policy")
+
+
+def leg_roofline(n, n_local, H, kern_ms):
+    alg = rollout_algorithmic_bytes(n, n_local, H)
+    ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms else None
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBPS if ach else None, "algorithmic_bytes": alg,
+            "kernel": rollout_kernel_name(n), "kernel_ms": kern_ms,
+            "issue_bound": issue_bound(n, H, kern_ms)}
+
+
+def aux_ars_shard(sw, torch, n, H, directions, device, iters=12):
+    """One GPU's shard of a sharded config (configs[3]: n = 3, configs[4]: n = 6; 2048
+    directions over 8 GPUs = 256 per GPU) as a self-contained ARS iteration loop."""
+    import numpy as np
     state = np.random.get_state()
-    agent = sw.ARSAgent(ep, ap, seed=0, device=device, full_covariance=True)
-    for _ in range(3):
-        agent.run_iteration_async(want_returns=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        agent.run_iteration_async(want_returns=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    leg = ArsLeg(sw, torch, n, H, directions, device)
+    r = leg.run(3, iters, torch.cuda.synchronize, time_every=4, postpass=8)
+    leg.check(0)
     np.random.set_state(state)
-    del agent
-    return {"directions": directions, "ms_per_iteration": dt * 1e3,
-            "env_steps_per_s": 2 * directions * H / dt}
+    dt = r["seconds"] / iters
+    return {"segments": n, "directions": directions, "ms_per_iteration": dt * 1e3,
+            "env_steps_per_s": 2 * directions * H / dt,
+            "roofline": leg_roofline(n, directions, H, r["kernel_ms"])}
 
 
-def main():
-    args = parse()
+def run_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
-                             "(one process per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # Rehearsal knobs (never set by the driver): run the multi-rank code path on a one-GPU box,
     # every rank on cuda:0 with gloo staged through the host instead of RCCL.
     backend = os.environ.get("SWIMMER_BENCH_BACKEND", "nccl")
-    if os.environ.get("SWIMMER_BENCH_SINGLE_DEVICE"):
+    single_device = bool(os.environ.get("SWIMMER_BENCH_SINGLE_DEVICE"))
+    if single_device:
         local = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows "
+                         f"{torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
@@ -194,102 +381,136 @@ def main():
     # follows the caller's current stream.
     torch.cuda.set_stream(torch.cuda.Stream(device))
 
-    n, H = args.segments, args.horizon
-    N = args.directions * world
-    ep = sw.EnvParam("LeonSwimmer-Bench", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
-    ap = sw.ARSParam("Bench", V1=False, n_iter=args.steps, H=H, N=N, b=N, alpha=0.0075, nu=0.01,
-                     safe=False, threshold=0, initial_w="Zero")
-    agent = sw.ARSAgent(ep, ap, seed=0, device=device, full_covariance=True)
-
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        agent.run_iteration_async(want_returns=False)
-    sync()
-    # HIP events on the launch stream around every 8th rollout launch of the timed region: a
-    # timed launch costs ~10 us of pipeline bubbles (measured), so timing all of them would
-    # slow the very loop being measured by 3 %
-    agent._pipe.timing(TIME_EVERY)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        agent.run_iteration_async(want_returns=False)
-    sync()
-    dt = time.perf_counter() - t0
-    kern_ms, kern_launches = agent._pipe.rollout_ms()
-    agent._pipe.timing(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    def same_policy_everywhere(agent, what):
         # every rank must hold the same policy (redundant deterministic update)
         pol = torch.as_tensor(agent.policy)
         ref = pol.clone() if backend != "nccl" else pol.to(device)
         mine = ref.clone()
         dist.broadcast(ref, src=0)
         if not torch.equal(ref, mine):
-            raise SystemExit(f"rank {rank}: policy differs from rank 0 after {args.steps} iterations")
-    bad = int((agent._status != 0).sum().item())
-    if bad or not np.isfinite(agent.policy).all():
-        raise SystemExit(f"bench produced {bad} bad rollouts / non-finite policy")
+            raise SystemExit(f"rank {rank}: policy differs from rank 0 after the {what} loop")
+
+    n, H = args.segments, args.horizon
+    N = args.directions * world if args.scaling == "weak" else args.total_directions
+    leg = ArsLeg(sw, torch, n, H, N, device)
+    agent = leg.agent
+    res = leg.run(args.warmup, args.steps, sync)
+    dt = max_over_ranks(res["seconds"])
+    if world > 1:
+        same_policy_everywhere(agent, "timed")
+    leg.check(rank)
+
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_aux:
+        # the fixed-size problem of configs[3] / [4] on the same ranks (strong scaling), so one
+        # driver run per N yields both curves
+        sleg = ArsLeg(sw, torch, n, H, args.total_directions, device)
+        sres = sleg.run(3, 12, sync, postpass=8)
+        sdt = max_over_ranks(sres["seconds"]) / 12
+        same_policy_everywhere(sleg.agent, "strong-scaling")
+        sleg.check(rank)
+        strong = {"directions_total": args.total_directions,
+                  "directions_per_gpu": sleg.agent.chunk, "ms_per_iteration": sdt * 1e3,
+                  "env_steps_per_s": 2 * args.total_directions * H / sdt,
+                  "kernel_ms": sres["kernel_ms"], "collective_us": sres.get("collective_us")}
+        del sleg
 
     if rank == 0:
         steps_per_iter = 2 * N * H
         value = steps_per_iter * args.steps / dt
         d = 2 * n + 2
-        assert kern_launches == -(-args.steps // TIME_EVERY)
+        kern_ms = res["kernel_ms"]
+        assert res["kernel_samples_timed_region"] == -(-args.steps // TIME_EVERY)
         local_steps = 2 * agent.n_local * H
-        # algorithmic HBM bytes of one rollout launch: every post-step state is
-        # materialised (8 d bytes per env-step, as the reference does, ars/environment.py:53)
-        # + per rollout its delta row (8 m d), return (8) and status (4)
-        alg_bytes = local_steps * 8 * d + 2 * agent.n_local * (8 * (n - 1) * d + 12)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        roof = leg_roofline(n, agent.n_local, H, kern_ms)
         flops_per_step = {3: 330.0, 6: 1100.0}.get(n, 40.0 * n * n)  # fp64 flop count, DESIGN.md
-        traffic = pmc_traffic("rollout_quad3_kernel<true,true,true>", n, args.directions, H)
+        traffic = pmc_traffic(rollout_kernel_name(n), n, agent.n_local, H)
+        cov_alg = local_steps * 8 * d       # the ride-along covariance pass reads every state once
+        roof.update({
+            "traffic": (traffic or {}).get("traffic_bytes"),
+            "traffic_breakdown": (traffic or {}).get("breakdown"),
+            "traffic_source": (traffic or {}).get("source"),
+            # the launch does TWO jobs: this iteration's rollouts (the bytes `achieved` counts)
+            # and the covariance pass over the previous iteration's trajectories (extra
+            # workgroups of the same grid).  Against the algorithmic bytes of both, the counters
+            # show no wasted traffic:
+            "algorithmic_bytes_with_covariance_pass": roof["algorithmic_bytes"] + cov_alg,
+            "traffic_over_algorithmic": (traffic["traffic_bytes"] / (roof["algorithmic_bytes"] + cov_alg)
+                                         if traffic else None),
+            "kernel_ms_timed_region": res["kernel_ms_timed_region"],
+            "kernel_samples_timed_region": res["kernel_samples_timed_region"],
+            "kernel_ms_postpass": res.get("kernel_ms_postpass"),
+            "kernel_samples": res["kernel_samples"],
+            "note": "the fused rollout is fp64-VALU-issue bound by construction (state, policy and "
+                    "sums stay in registers; see issue_bound); HBM is the contract's roofline. "
+                    "The HBM-bound regimes of this path are aux.step_only (step kernel, >= 1e6 "
+                    "envs) and aux.rollout_saturated (rollouts filling the chip).  kernel_ms = "
+                    "mean over the sampled launches of the timed region and every launch of an "
+                    "untimed post-pass",
+            "fp64_tflops": local_steps * flops_per_step / (kern_ms * 1e-3) / 1e12,
+            "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS})
+        if args.scaling == "weak":
+            workload = (f"ARS V2 iteration, {n}-segment swimmer, {args.directions} directions/GPU x 2 "
+                        f"rollouts x H={H} (BASELINE configs[2] per GPU)")
+        else:
+            workload = (f"ARS V2 iteration, {n}-segment swimmer, {N} directions in all x 2 rollouts x "
+                        f"H={H}, sharded over {world} GPU(s) (BASELINE configs[{3 if n == 3 else 4}])")
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"ARS V2 iteration, {n}-segment swimmer, "
-                                   f"{args.directions} directions/GPU x 2 rollouts x H={H} "
-                                   f"(BASELINE configs[2] per GPU)",
-                       "directions_total": N, "horizon": H, "segments": n,
-                       "trajectory_capture": True, "full_covariance": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload,
+                       "directions_total": N, "directions_per_gpu": agent.chunk, "horizon": H,
+                       "segments": n, "trajectory_capture": True, "full_covariance": True,
                        "parallelism": f"directions sharded over {world} GPU(s), "
-                                      "1 all-gather/iteration"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": (traffic or {}).get("traffic_bytes"),
-                         "traffic_breakdown": (traffic or {}).get("breakdown"),
-                         "algorithmic_bytes": alg_bytes,
-                         "kernel": ("rollout_quad3_kernel<true,true,true>" if n == 3
-                                    else f"rollout_row_kernel<{n},true,true,true>" if n >= 4
-                                    else f"rollout_kernel<{n},true,false>"),
-                         "kernel_ms": kern_ms,
-                         "note": "the fused rollout is fp64-VALU-latency bound by construction "
-                                 "(state, policy and sums stay in registers); HBM is the "
-                                 "contract's roofline, see DESIGN.md and aux.step_only; the launch "
-                                 "also carries the covariance pass over the previous iteration's "
-                                 "trajectories (traffic_breakdown), achieved counts the rollouts' "
-                                 "bytes only",
-                         "fp64_tflops": local_steps * flops_per_step / (kern_ms * 1e-3) / 1e12,
-                         "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                         "issue_bound": issue_bound(n, H, kern_ms)},
+                                      "1 all-gather/iteration",
+                       "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                       "backend": (dist.get_backend() if world > 1 else None)},
+            "roofline": roof,
         }
-        # the step-only sweep and the CPU baseline belong to the N = 1 line only
+        aux = {}
+        if world > 1:
+            aux["collective_us"] = res.get("collective_us")
+            if strong:
+                aux["strong_2048_directions"] = strong
+        # the step-only sweep, the shard legs and the CPU baseline belong to the N = 1 line only
         if not args.no_aux and world == 1:
-            line["aux"] = {"step_only": aux_step_only(sw, n, device),
-                           "ars_2048_directions_one_gpu": aux_more_directions(sw, n, H, device)}
+            aux["step_only"] = aux_step_only(sw, torch, n, device)
+            s2048 = aux_ars_shard(sw, torch, n, H, 2048, device)
+            aux["ars_2048_directions_one_gpu"] = s2048     # configs[3]'s whole problem on ONE GPU
+            aux["shard_n3_256_directions"] = aux_ars_shard(sw, torch, 3, H, 256, device)
+            aux["shard_n6_256_directions"] = aux_ars_shard(sw, torch, 6, H, 256, device)
+            aux["rollout_saturated"] = aux_rollout_saturated(sw, torch, device)
+        if aux:
+            line["aux"] = aux
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, H, args.directions, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SW_ABI_VERSION 1
+#define SW_ABI_VERSION 2
 #define SW_MAX_SEGMENTS 8 /* kernels are instantiated for n = 2..8 */
 
 /* status codes (return values) */
@@ -147,8 +147,11 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
  *                   divisor (ars_agent.py:176-177, :126-128);  > 0 -> only the top_b
  *                   directions by max(r+, r-) are used (safe_ars/ars.py:95-96)
  *   moments       : NULL (V1) or [n_moment_rows][2d] partial sums of this iteration
- *   running       : NULL (V1) or [1 + 2d] running {count, sum(s-c), sum((s-c)^2)} over the
- *                   whole training, updated in place (ars_agent.py:171, :180: never cleared)
+ *   running       : NULL (V1) or [1 + 2d] statistics of every state since training began
+ *                   (ars_agent.py:171, :180: never cleared): {count n, mean - c (d),
+ *                   M2 = sum (s - mean)^2 (d)}, c = reset state; zero before the first call.
+ *                   Each iteration's batch is merged in (Chan et al. pairwise update): no
+ *                   cancellation that grows with the length of training
  *   n_new_states  : states added this iteration (2 * n_dir * H over all ranks)
  *   mean, inv_std : NULL (V1) or [d] each, overwritten with the new mean and
  *                   var ** -0.5 (var with ddof = 1, np.cov's default)
@@ -172,8 +175,13 @@ int sw_ars_update_gathered_f64(const sw_params *p, int64_t n_dir, const double *
 
 /* Full first and second moments of recorded trajectories (for the `covariance` attribute):
  * acc[0] += count, acc[1..d] += sum(s - c), acc[1+d + f*d + g] += sum((s-c)_f (s-c)_g),
- * over traj [H][d][n_roll]; acc is [1 + d + d*d] and must be zeroed by the caller before
- * the first call.  HBM-bound: reads the trajectory buffer exactly once. */
+ * over traj [H][d][n_roll].  HBM-bound: reads the trajectory buffer exactly once.
+ * acc holds sw_cov_acc_doubles(p, n_roll, H) doubles: the 1 + d + d*d sums, then the pass's
+ * scratch (a ticket counter and one row of partial sums per tile); the caller zeroes ALL of it
+ * before the first call and leaves the scratch part alone afterwards.  No floating-point atomics:
+ * the tile that finishes last adds the rows in tile order, so the same call on the same data
+ * gives the same bits.  Passes over one acc must be stream-ordered (one at a time). */
+int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H);
 int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
                         double *acc, void *stream);
 
@@ -190,8 +198,12 @@ int sw_mt19937_uniform_pm1(uint32_t *key, int32_t *pos, int64_t n, double *out);
  * Replaces the serial body of ARSAgent.runOneIteration (ars/ars_agent.py:137-182) with a
  * schedule over a ring of SW_PIPELINE_SLOTS buffer sets.  A pipeline owns one extra HIP stream
  * (H2D copies of the deltas) and 64 bytes of pinned host memory (a progress flag); it owns no
- * device memory: every buffer is passed per call, one set per `slot` (= iteration index mod
- * SW_PIPELINE_SLOTS; use the pipeline with ONE stream).  The caller's stream carries kernels
+ * device memory: every buffer is passed per call, one set per `slot`.  The slot of a call is
+ * sw_ars_pipeline_next_slot() = (number of sw_ars_iteration_rollouts_f64 calls so far) mod
+ * SW_PIPELINE_SLOTS -- the pipeline's own count, so that a caller's iteration counter (reset by
+ * a checkpoint load, say) can never shift the ring; a call with another slot is refused with
+ * SW_ERR_SIZE.  Every rank calls once per iteration, also with an empty shard (n_dir = 0: nothing
+ * but the progress flag is launched).  Use the pipeline with ONE stream.  The caller's stream carries kernels
  * only -- no cross-stream waits, no event records: every rollout launch stores its index to the
  * progress flag when it starts, and the host paces buffer reuse on that.
  *
@@ -199,7 +211,8 @@ int sw_mt19937_uniform_pm1(uint32_t *key, int32_t *pos, int64_t n, double *out);
  *                                   caller's stream: ONE launch = the 2*n_dir rollouts of this
  *                                   rank's shard + (extra workgroups) the covariance pass
  *                                   sw_traj_moments_f64 over the PREVIOUS call's traj -> its
- *                                   cov_acc; this call's traj is owed a pass (if cov_acc given)
+ *                                   cov_acc; this call's traj is owed a pass (if cov_acc given;
+ *                                   cov_acc: sw_cov_acc_doubles(p, 2*n_dir, H) doubles, zeroed)
  *   ... caller all-gathers its segment [returns | moment rows] between ranks ...
  *   sw_ars_iteration_update_f64     caller's stream: sw_ars_update_gathered_f64 on the gathered
  *                                   buffer
@@ -213,6 +226,7 @@ typedef struct sw_ars_pipeline sw_ars_pipeline;
 int sw_ars_pipeline_create(sw_ars_pipeline **out);
 void sw_ars_pipeline_destroy(sw_ars_pipeline *pl);
 int sw_ars_pipeline_slots(void);
+int sw_ars_pipeline_next_slot(sw_ars_pipeline *pl);
 int sw_ars_pipeline_host_slot_wait(sw_ars_pipeline *pl, int slot);
 int sw_ars_pipeline_sync_cov(sw_ars_pipeline *pl);
 /* enable = k > 0: record HIP events around every k-th rollout launch on its stream (resets the

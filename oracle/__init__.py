@@ -5,5 +5,5 @@ package; the product package never does (tests/test_no_oracle_in_product.py enfo
 """
 from .swimmer_oracle import (  # noqa: F401
     OracleParams, build, accelerations, step, reset, rollout, step_batch, rollout_batch,
-    num_threads, set_num_threads, cpu_share, twin_accelerations, twin_step, twin_step_batch,
+    num_threads, set_num_threads, cpu_share, twin_accelerations, twin_step, twin_step_batch, twin_system,
 )

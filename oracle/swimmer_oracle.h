@@ -36,6 +36,8 @@ int swo_rollout_batch(const swo_params *p, long n_roll, int H, const double *pol
 /* native twin (rlglue/environment/SwimmerEnvironment.cpp), twin_oracle.c */
 int swt_accelerations(const swo_params *p, const double *state, const double *u,
                       double *gdd, double *tdd);
+int swt_system(const swo_params *p, const double *state, const double *u, double *A_out,
+               double *B_out, double *X_out);
 int swt_step(const swo_params *p, const double *state, const double *u,
              double *next, double *reward);
 int swt_step_batch(const swo_params *p, long n_env, const double *states,

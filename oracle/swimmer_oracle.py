@@ -52,6 +52,7 @@ def _load():
         lib.swo_rollout_batch.argtypes = [pp, ctypes.c_long, ctypes.c_int, dp, dp, dp, dp, dp]
         lib.swt_accelerations.argtypes = [pp, dp, dp, dp, dp]
         lib.swt_step.argtypes = [pp, dp, dp, dp, dp]
+        lib.swt_system.argtypes = [pp, dp, dp, dp, dp, dp]
         lib.swt_step_batch.argtypes = [pp, ctypes.c_long, dp, dp, dp, dp]
         lib.swo_num_threads.restype = ctypes.c_int
         lib.swo_set_num_threads.argtypes = [ctypes.c_int]
@@ -165,6 +166,15 @@ def twin_accelerations(p, state, u):
     tdd = np.empty(p.n)
     _check(_load().swt_accelerations(ctypes.byref(p), _p(state), _p(u), _p(gdd), _p(tdd)))
     return gdd, tdd
+
+
+def twin_system(p, state, u):
+    """The native env's dense (5n+2) system as assembled, and its solution: (A, B, X)."""
+    nn = 5 * p.n + 2
+    state, u = _c(state), _c(u)
+    A, B, X = np.empty((nn, nn)), np.empty(nn), np.empty(nn)
+    _check(_load().swt_system(ctypes.byref(p), _p(state), _p(u), _p(A), _p(B), _p(X)))
+    return A, B, X
 
 
 def twin_step(p, state, u):

@@ -91,19 +91,17 @@ static void twin_friction(const swo_params *p, const double *Gd, const double *t
     }
 }
 
-/* compute_accelerations (:139-226) */
-int swt_accelerations(const swo_params *p, const double *state, const double *u,
-                      double *gdd, double *tdd)
+/* the dense system A X = B of compute_accelerations (:139-211), unknowns
+ * X = (thdd_1..n | f_0x f_0y .. f_nx f_ny | Gdd_1x Gdd_1y .. Gdd_nx Gdd_ny) */
+static void twin_assemble(const swo_params *p, const double *state, const double *u,
+                          double A[][DIM], double *B)
 {
     const int n = p->n;
-    if (n < 1 || n > NMAX) return -1;
     const int nn = 5 * n + 2;
     const double l = p->l_i, m = p->m_i;
     double th[NMAX], thd[NMAX], F[NMAX][2], Mf[NMAX];
     for (int i = 0; i < n; ++i) { th[i] = state[2 + 2 * i]; thd[i] = state[3 + 2 * i]; }
     twin_friction(p, state, th, thd, F, Mf);
-    static _Thread_local double A[DIM][DIM];
-    double B[DIM];
     for (int i = 0; i < nn; ++i) { memset(A[i], 0, sizeof(double) * (size_t)nn); B[i] = 0.0; }
     for (int i = 1; i <= n; ++i) {                               /* :151-164 */
         A[i - 1][i - 1] = m * pow(l, 2.0) / 12.0;
@@ -142,6 +140,18 @@ int swt_accelerations(const swo_params *p, const double *state, const double *u,
                 B[row] = l / 2 * (sin(th[i - 1]) * pow(thd[i - 1], 2.0) + sin(th[i]) * pow(thd[i], 2.0));
             }
         }
+}
+
+/* compute_accelerations (:139-226) */
+int swt_accelerations(const swo_params *p, const double *state, const double *u,
+                      double *gdd, double *tdd)
+{
+    const int n = p->n;
+    if (n < 1 || n > NMAX) return -1;
+    const int nn = 5 * n + 2;
+    static _Thread_local double A[DIM][DIM];
+    double B[DIM];
+    twin_assemble(p, state, u, A, B);
     if (lu_solve(nn, A, B)) return 1;
     gdd[0] = gdd[1] = 0.0;
     for (int i = 1; i <= n; ++i) {                               /* :222-225 */
@@ -149,6 +159,26 @@ int swt_accelerations(const swo_params *p, const double *state, const double *u,
         gdd[0] += 1.0 / n * B[3 * n + 2 * i];
         gdd[1] += 1.0 / n * B[3 * n + 2 * i + 1];
     }
+    return 0;
+}
+
+/* The assembled system and its solution, row-major A [nn][nn], B [nn], X [nn] (nn = 5n+2):
+ * what the reference's test driver prints (rlglue/test/acceleration-compare.txt:27-100). */
+int swt_system(const swo_params *p, const double *state, const double *u, double *A_out,
+               double *B_out, double *X_out)
+{
+    const int n = p->n;
+    if (n < 1 || n > NMAX) return -1;
+    const int nn = 5 * n + 2;
+    static _Thread_local double A[DIM][DIM];
+    double B[DIM];
+    twin_assemble(p, state, u, A, B);
+    for (int i = 0; i < nn; ++i) {
+        memcpy(A_out + (size_t)i * nn, A[i], sizeof(double) * (size_t)nn);
+        B_out[i] = B[i];
+    }
+    if (lu_solve(nn, A, B)) return 1;
+    memcpy(X_out, B, sizeof(double) * (size_t)nn);
     return 0;
 }
 

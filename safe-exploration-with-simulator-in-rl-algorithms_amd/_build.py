@@ -8,7 +8,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SWIMMER_HIP_LIB") or os.path.join(CSRC, "libswimmer_hip.so")  # override: experiments
 SOURCES = ["swimmer_kernels.hip", "host_rng.cpp"]
 HEADERS = ["rlglue_env.cpp", os.path.join("..", "..", "include", "rlglue_swimmer.h"),
-           "swimmer_device.h", "swimmer_quad3.h", "swimmer_row.h", "swimmer_twin.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
+           "swimmer_device.h", "swimmer_quad3.h", "swimmer_row.h", "swimmer_row_fused.h", "swimmer_twin.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 
 

@@ -12,7 +12,7 @@ import torch  # imported before the library so that both share one libamdhip64
 
 from . import _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SEGMENTS = 8
 
 ERR_NAMES = {0: "SW_OK", 1: "SW_ERR_NULL", 2: "SW_ERR_SEGMENTS", 3: "SW_ERR_SIZE",
@@ -82,11 +82,13 @@ _PROTOTYPES = {
                                          ctypes.c_void_p]),
     "sw_traj_moments_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sw_cov_acc_doubles": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
     "sw_mt19937_uniform_pm1": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
                                               ctypes.c_int64, ctypes.c_void_p]),
     "sw_ars_pipeline_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "sw_ars_pipeline_destroy": (None, [ctypes.c_void_p]),
     "sw_ars_pipeline_slots": (ctypes.c_int, []),
+    "sw_ars_pipeline_next_slot": (ctypes.c_int, [ctypes.c_void_p]),
     "sw_ars_pipeline_host_slot_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "sw_ars_pipeline_sync_cov": (ctypes.c_int, [ctypes.c_void_p]),
     "sw_ars_pipeline_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

@@ -12,7 +12,10 @@ drawn as 2*rand(m, d)-1, ars_agent.py:95,137).  What differs is where the work h
   * sigma_R, the policy step and the running V2 statistics are ONE launch of
     sw_ars_update_f64, run redundantly and deterministically on every rank;
   * the full state covariance (only its diagonal feeds the policy, ars/environment.py:32)
-    is one HBM-bound pass over the recorded trajectories (sw_traj_moments_f64).
+    is one HBM-bound pass over the recorded trajectories (sw_traj_moments_f64) that rides
+    along in the next iteration's rollout launch.  With more than one rank every rank holds
+    the sums of its own shard: `reduce_covariance()` is the (explicit) collective that adds
+    them up; the `covariance` attribute itself never communicates.
 
 The safe-exploration gate (ars_agent.py:144-157) is sequential by construction and is not
 part of this path: agent_param.safe=True raises NotImplementedError.
@@ -83,14 +86,19 @@ class ARSAgent(object):
         self._mean = torch.zeros(self.d, **f64) if self.v2 else None
         self._inv_std = torch.ones(self.d, **f64) if self.v2 else None
         self._running = torch.zeros(1 + 2 * self.d, **f64) if self.v2 else None
-        self._cov_acc = torch.zeros(1 + self.d + self.d * self.d, **f64) \
-            if self.full_covariance else None
         self._sigma = torch.zeros(1, **f64)
         self.n_saved_states = 0
 
         N, H = agent_param.N, agent_param.H
         self.lo, self.hi, self.chunk = shard_bounds(N, self.rank, self.world)
         self.n_local = self.hi - self.lo
+        # covariance sums of this rank's shard [count | sum x | sum x x^T] + the pass's scratch
+        self._cov_sums = 1 + self.d + self.d * self.d
+        self._cov_acc = (kernels.new_cov_acc(self.params, 2 * self.n_local, H, self.device)
+                         if self.full_covariance else None)
+        self._coll_events = None
+        self._cov_total = None       # all ranks' sums as of iteration _cov_total_it (world > 1)
+        self._cov_total_it = -1
         self.rows_chunk = kernels.moments_blocks(2 * self.chunk) if self.v2 else 0
         # Ring-buffered pipeline (slot = iteration mod ring depth), enqueued from native code
         # (sw_ars_pipeline, include/swimmer_hip.h):
@@ -147,25 +155,63 @@ class ARSAgent(object):
     @property
     def covariance(self):
         """np.cov(all saved states) (ddof = 1, ars_agent.py:182).  The diagonal is the one
-        the policy whitening uses; off-diagonals need full_covariance=True."""
+        the policy whitening uses; off-diagonals need full_covariance=True.
+
+        Never communicates.  With one rank it is always current.  With several ranks the
+        off-diagonal sums are spread over the ranks: call `reduce_covariance()` on EVERY rank
+        (a collective) after the iteration whose value is wanted; reading the attribute at any
+        other time raises instead of blocking in a collective the other ranks never enter."""
         if not self.v2:
             return None
         if self.n_saved_states == 0:
             return np.identity(self.d)
-        var = self._inv_std.cpu().numpy() ** -2.0
         if not self.full_covariance:
-            return np.diag(var)
+            return np.diag(self._inv_std.cpu().numpy() ** -2.0)
+        if self.world == 1:
+            self._pipe.sync_cov()
+            return self._cov_matrix(self._cov_acc[:self._cov_sums].cpu().numpy())
+        if self._cov_total_it != self._it:
+            raise SwimmerHipError(
+                "covariance: the off-diagonal sums live on all ranks; call reduce_covariance() "
+                "on every rank after the iteration (collective) before reading the attribute")
+        return self._cov_matrix(self._cov_total)
+
+    def reduce_covariance(self):
+        """COLLECTIVE: add up every rank's covariance sums (they are linear) and return the
+        covariance matrix; `covariance` then returns the same matrix on every rank until
+        the next iteration.  A no-op beyond the local flush with one rank."""
+        if not (self.v2 and self.full_covariance) or self.n_saved_states == 0:
+            return self.covariance
         self._pipe.sync_cov()
-        acc = self._cov_acc
-        if self.world > 1:   # sums are linear: reduce the per-rank partial sums only when read
+        acc = self._cov_acc[:self._cov_sums]
+        if self.world > 1:
             acc = acc.cpu() if dist.get_backend(self.group) == "gloo" else acc.clone()
             dist.all_reduce(acc, group=self.group)
-        acc = acc.cpu().numpy()
+        self._cov_total = acc.cpu().numpy()
+        self._cov_total_it = self._it
+        return self._cov_matrix(self._cov_total)
+
+    def _cov_matrix(self, acc):
         n, s1 = acc[0], acc[1:1 + self.d]
         s2 = acc[1 + self.d:].reshape(self.d, self.d)
         cov = (s2 - np.outer(s1, s1) / n) / (n - 1.0)
-        cov[np.diag_indices(self.d)] = var
+        # the diagonal is the one the policy uses: the V2 running statistics
+        cov[np.diag_indices(self.d)] = self._inv_std.cpu().numpy() ** -2.0
         return cov
+
+    # ---- measurement aid: device time of the per-iteration all-gather ------------------
+    def collective_timing(self, on):
+        """HIP events on the launch stream around every all-gather from now on (off: None).
+        Each pair costs a few microseconds of pipeline bubbles: keep it out of timed loops."""
+        self._coll_events = [] if on else None
+
+    def collective_us(self):
+        """Mean device time between the end of the rollout launch and the start of the update,
+        i.e. the all-gather as the critical stream sees it; None without samples."""
+        if not self._coll_events:
+            return None
+        torch.cuda.synchronize(self.device)
+        return 1e3 * sum(a.elapsed_time(b) for a, b in self._coll_events) / len(self._coll_events)
 
     # ---- pieces of an iteration -----------------------------------------------------
     def sample_deltas(self):
@@ -194,9 +240,12 @@ class ARSAgent(object):
         device tensor (a view of the result segment, valid until the next iteration), or
         None with want_returns=False."""
         ap = self.agent_param
-        i = self._it % self._pipe.slots
+        i = self._pipe.next_slot()               # the pipeline's own count, not self._it
         self._it += 1
         self._pipe.host_slot_wait(i)             # the slot's previous user is done with it
+        if self.record_trajectories:
+            # the policy the rollouts are about to run with (the update below overwrites it)
+            self._policy_snapshot = self._policy.cpu().numpy()
         host = self._deltas_host_np[i]
         if deltas is None:      # the same draws as sample_deltas(), generated natively
             numpy_global_uniform_pm1(host)
@@ -208,7 +257,15 @@ class ARSAgent(object):
                             self._mean, self._inv_std, self._returns_local, self._traj,
                             self._moments_local,
                             self._cov_acc if self._traj is not None else None, self._status)
-        gathered = all_gather_segments(self._send, self._gathered, self.world, self.group)
+        if self._coll_events is not None and self.world > 1:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gathered = all_gather_segments(self._send, self._gathered, self.world, self.group)
+            e1.record()
+            self._coll_events.append((e0, e1))
+        else:
+            gathered = all_gather_segments(self._send, self._gathered, self.world, self.group)
         n_new = 2 * ap.N * ap.H
         self._pipe.update(i, self.params, ap.N, gathered, self.world, self.chunk,
                           self.rows_chunk, self._deltas, self._policy, ap.alpha, ap.b,
@@ -234,17 +291,19 @@ class ARSAgent(object):
         return out
 
     # ---- checkpoint / resume (the reference only saves the policy, ars_agent.py:218-219) ----
+    CHECKPOINT_FORMAT = 2   # 2: running = {n, mean - c, M2};  1: raw sums {n, S1, S2} (converted)
+
     def save_checkpoint(self, path):
-        """Everything needed to continue training bit for bit: policy, V2 running sums,
+        """Everything needed to continue training bit for bit: policy, V2 running statistics,
         covariance sums, iteration count and NumPy's global generator state.  Plain arrays
         in an .npz (no pickle).  Collective when distributed; rank 0 writes."""
         torch.cuda.synchronize(self.device)
-        self._pipe.sync_cov()
         kind, key, pos, has_gauss, cached = np.random.get_state()
         assert kind == "MT19937"
         cov = None
         if self.full_covariance:
-            cov = self._cov_acc
+            self._pipe.sync_cov()
+            cov = self._cov_acc[:self._cov_sums]
             if self.world > 1:
                 cov = cov.cpu() if dist.get_backend(self.group) == "gloo" else cov.clone()
                 dist.all_reduce(cov, group=self.group)
@@ -253,7 +312,7 @@ class ARSAgent(object):
             data = dict(policy=self.policy, n_saved_states=np.int64(self.n_saved_states),
                         iteration=np.int64(self._it), rng_key=key, rng_pos=np.int64(pos),
                         rng_has_gauss=np.int64(has_gauss), rng_cached=np.float64(cached),
-                        v2=np.int64(self.v2))
+                        v2=np.int64(self.v2), format=np.int64(self.CHECKPOINT_FORMAT))
             if self.v2:
                 data.update(mean=self._mean.cpu().numpy(), inv_std=self._inv_std.cpu().numpy(),
                             running=self._running.cpu().numpy())
@@ -266,27 +325,36 @@ class ARSAgent(object):
         z = np.load(path, allow_pickle=False)
         if bool(z["v2"]) != self.v2 or z["policy"].shape != (self.m, self.d):
             raise SwimmerHipError("checkpoint does not match this agent's configuration")
+        # nothing of this agent's earlier iterations may still be in flight: the buffers below
+        # are read by queued kernels (the update of the last iteration, an owed covariance pass)
+        if self.full_covariance:
+            self._pipe.sync_cov()
+        torch.cuda.synchronize(self.device)
         dev = self.device
         self._policy.copy_(torch.as_tensor(z["policy"], device=dev))
         if self.v2:
+            running = np.array(z["running"], dtype=np.float64)
+            if "format" not in z.files or int(z["format"]) < 2:
+                # round-1 files hold raw sums about the pivot: {n, S1, S2} -> {n, S1/n, S2 - S1^2/n}
+                n, s1, s2 = running[0], running[1:1 + self.d], running[1 + self.d:]
+                if n > 0:
+                    running = np.concatenate(([n], s1 / n, s2 - s1 * (s1 / n)))
             self._mean.copy_(torch.as_tensor(z["mean"], device=dev))
             self._inv_std.copy_(torch.as_tensor(z["inv_std"], device=dev))
-            self._running.copy_(torch.as_tensor(z["running"], device=dev))
+            self._running.copy_(torch.as_tensor(running, device=dev))
         if self.full_covariance:
-            self._pipe.sync_cov()
+            self._cov_acc.zero_()
             if "cov_acc" in z.files and self.rank == 0:   # per-rank sums add up to the total
-                self._cov_acc.copy_(torch.as_tensor(z["cov_acc"], device=dev))
-            else:
-                self._cov_acc.zero_()
+                self._cov_acc[:self._cov_sums].copy_(torch.as_tensor(z["cov_acc"], device=dev))
+        self._cov_total_it = -1
         self.n_saved_states = int(z["n_saved_states"])
         self._it = int(z["iteration"])
         np.random.set_state(("MT19937", z["rng_key"], int(z["rng_pos"]), int(z["rng_has_gauss"]),
                              float(z["rng_cached"])))
+        torch.cuda.synchronize(self.device)
 
     def runOneIteration(self):
         """One whole ARS iteration (ars_agent.py:132-185); returns the list of 2N returns."""
-        if self.record_trajectories:
-            self._policy_snapshot = self.policy
         rets = self.run_iteration_async()
         out = rets.cpu().numpy()
         if int((self._status != 0).sum().item()):
@@ -308,8 +376,10 @@ class ARSAgent(object):
                     print(f"[seed {self.n_seed}] ARS {variant} n={ep.n} N={ap.N} b={ap.b} "
                           f"alpha={ap.alpha} nu={ap.nu} h={ep.h} l_i={ep.l_i} m_i={ep.m_i} | "
                           f"iteration {j}/{ap.n_iter}: mean return {r}")
-                if save_data_path is not None and self.rank == 0:
-                    self.database.save(save_data_path)
+                if save_data_path is not None:
+                    # one rank: the reference's single file; several ranks: every rank stores the
+                    # rollouts of its own shard (Database.shard_path / Database.load reads them all)
+                    self.database.save(save_data_path, rank=self.rank, world=self.world)
         self.real_world.close()
         if save_policy_path is not None and self.rank == 0:
             np.save(save_policy_path, self.policy)

@@ -55,10 +55,34 @@ class Database(object):
         self._device_batches.append((traj, policies))
         self.size += traj.shape[2]
 
-    def save(self, path):
+    @staticmethod
+    def shard_path(path, rank, world):
+        """File holding rank `rank`'s rollouts when `world` ranks share a training run."""
+        stem = path[:-4] if path.endswith(".npz") else path
+        return f"{stem}.rank{rank:03d}of{world:03d}.npz"
+
+    def save(self, path, rank=0, world=1):
+        """The reference's single .npz (database.py:36-37).  With several ranks each rank holds
+        the rollouts of its own direction shard (65 MB per iteration and rank at the BASELINE
+        sizes -- gathering them would cost more than the iterations): every rank writes
+        shard_path(path, rank, world), and load(path) reads the shards back in rank order."""
+        if world > 1:
+            path = self.shard_path(path, rank, world)
         np.savez(path, policies=self.policies, trajectories=self.trajectories)
 
     def load(self, path):
+        import glob
+        import os
+        if not os.path.exists(path) and not os.path.exists(path + ".npz"):
+            stem = path[:-4] if path.endswith(".npz") else path
+            shards = sorted(glob.glob(glob.escape(stem) + ".rank[0-9][0-9][0-9]of[0-9][0-9][0-9].npz"))
+            if shards:
+                for shard in shards:
+                    self._load_one(shard)
+                return
+        self._load_one(path if os.path.exists(path) else path + ".npz")
+
+    def _load_one(self, path):
         with np.load(path, allow_pickle=False) as stored:
             missing = {"policies", "trajectories"} - set(stored.files)
             if missing:

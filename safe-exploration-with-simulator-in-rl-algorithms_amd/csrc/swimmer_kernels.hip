@@ -77,8 +77,12 @@ sw::TwinConsts make_twin_consts(const sw_params *p)
 
 inline bool is_twin(const sw_params *p) { return (p->flags & SW_FLAG_MODEL_TWIN) != 0; }
 
+// First call of every ABI entry point.  Also drops whatever error an earlier HIP call of this
+// thread left behind (a failed call of the caller's, hipErrorNotReady from an event query, ...):
+// launch_status() must report OUR launch, not blame a stale error on it.
 int check_params(const sw_params *p)
 {
+    (void)hipGetLastError();
     if (!p) return SW_ERR_NULL;
     if (p->n < 2 || p->n > SW_MAX_SEGMENTS) return SW_ERR_SEGMENTS;
     if (p->flags & ~(SW_FLAG_ROLLOUT_LANE | SW_FLAG_ROLLOUT_QUAD | SW_FLAG_MODEL_TWIN)) return SW_ERR_PARAM;
@@ -371,17 +375,46 @@ rollout_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_roll, int32_t H, const 
 }
 
 constexpr int kMomBlock = 256;
-constexpr int kMomTChunk = 32;  // steps per workgroup (8 measured slower: more atomics, less work per workgroup)
+constexpr int kMomTChunk = 32;  // steps per 256-thread tile (8 measured slower: less work per workgroup)
+constexpr uint32_t kCovMaxTiles = 4096;   // tiles per pass: bounds the fixed-order merge
+
+// Tiling of a covariance pass over traj [H][D][n_roll] for workgroups of `block` threads:
+// nbx tiles of `block` rollouts x ny tiles of tchunk steps.  A function of (n_roll, H, block)
+// only, so a pass always sums in the same order (bit-reproducible results).
+struct CovTiling {
+    uint32_t nbx, ny;
+    int32_t tchunk;
+};
+
+CovTiling cov_tiling(int64_t n_roll, int32_t H, int block)
+{
+    CovTiling t;
+    t.nbx = (uint32_t)((n_roll + block - 1) / block);
+    const int32_t base = (block >= kMomBlock) ? kMomTChunk : kMomTChunk * (kMomBlock / block) / 2;
+    const uint32_t ny_max = (uint32_t)((H + base - 1) / base);
+    const uint32_t cap = kCovMaxTiles / t.nbx > 0 ? kCovMaxTiles / t.nbx : 1u;
+    const uint32_t ny = ny_max < cap ? ny_max : cap;
+    t.tchunk = (int32_t)((H + (int32_t)ny - 1) / (int32_t)ny);
+    t.ny = (uint32_t)((H + t.tchunk - 1) / t.tchunk);
+    return t;
+}
+
+// acc buffer of a covariance pass: [count | sum x (D) | sum x x^T (D x D)] followed by the
+// pass's scratch: one ticket counter (a double slot whose first 4 bytes are the counter; all-zero
+// bits = 0) and one row of D + D*D partial sums per tile.
+__host__ __device__ constexpr int cov_sums(int D) { return 1 + D + D * D; }
 
 // One tile of the full first / second moment sums of a trajectory buffer [H][D][n_roll]:
-// BLOCK rollouts x the steps [t0, t1), accumulated into acc = [count | sum x (D) | sum x x^T (D x D)]
-// (x = state - reset pivot) with atomics.  Workgroups of any size that is a multiple of 64 can
-// run it: the standalone traj_moments_kernel and the covariance workgroups that ride along in a
-// rollout launch (SideJob).  For long chains the upper triangle is accumulated JB rows at a time
-// (re-reading the tile from cache) so that the accumulators stay in registers.
+// BLOCK rollouts x the steps [t0, t1) (x = state - reset pivot), written to the tile's scratch
+// row.  NO atomics on the sums: the tile that finishes last (ticket counter) adds all rows to acc
+// in tile order, so the result does not depend on the order the tiles ran in.  Workgroups of any
+// size that is a multiple of 64 can run it: the standalone traj_moments_kernel and the covariance
+// workgroups that ride along in a rollout launch (SideJob).  For long chains the upper triangle is
+// accumulated JB rows at a time (re-reading the tile from cache) so that the accumulators stay in
+// registers.
 template <int D, int BLOCK, int J0, int JB>
 __device__ __forceinline__ void moments_pass(int64_t n_roll, const double *__restrict__ traj,
-                                             double *__restrict__ acc, int64_t bx, int32_t t0, int32_t t1,
+                                             double *__restrict__ tile_row, int64_t bx, int32_t t0, int32_t t1,
                                              double *sh /* [BLOCK / 64][D + JB * D] */)
 {
     constexpr int NW = BLOCK / kWave, W = D + JB * D;
@@ -430,53 +463,81 @@ __device__ __forceinline__ void moments_pass(int64_t n_roll, const double *__res
         const bool live = (j < D) ? (J0 == 0) : (f < J1 && g >= f);
         if (!live) continue;
         double v = 0.0;
-        for (int i = 0; i < NW; ++i) v += sh[i * W + j];
-        if (j < D) {
-            atomicAdd(&acc[1 + j], v);
-        } else {   // mirror into both halves
-            atomicAdd(&acc[1 + D + f * D + g], v);
-            if (g != f) atomicAdd(&acc[1 + D + g * D + f], v);
-        }
+        for (int i = 0; i < NW; ++i) v += sh[i * W + j];   // fixed order over the waves
+        if (j < D) tile_row[j] = v;
+        else tile_row[D + f * D + g] = v;                   // upper triangle only
     }
 }
 
 template <int D, int BLOCK, int JB, int J0 = 0>
 struct MomentsPasses {
     static __device__ __forceinline__ void run(int64_t n_roll, const double *__restrict__ traj,
-                                               double *__restrict__ acc, int64_t bx, int32_t t0,
+                                               double *__restrict__ tile_row, int64_t bx, int32_t t0,
                                                int32_t t1, double *sh)
     {
         if constexpr (J0 < D) {
-            moments_pass<D, BLOCK, J0, JB>(n_roll, traj, acc, bx, t0, t1, sh);
-            MomentsPasses<D, BLOCK, JB, J0 + JB>::run(n_roll, traj, acc, bx, t0, t1, sh);
+            moments_pass<D, BLOCK, J0, JB>(n_roll, traj, tile_row, bx, t0, t1, sh);
+            MomentsPasses<D, BLOCK, JB, J0 + JB>::run(n_roll, traj, tile_row, bx, t0, t1, sh);
         }
     }
 };
 
+// Tile `tile` of `n_tiles` (tile = by * nbx + bx).  acc = [sums | counter | n_tiles rows].
 template <int D, int BLOCK>
 __device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const double *__restrict__ traj,
                                              double *__restrict__ acc, int64_t bx, int32_t t0, int32_t t1,
-                                             bool count_tile)
+                                             uint32_t tile, uint32_t n_tiles)
 {
     // rows of the upper triangle per pass: as many as keep the accumulators (D + the rows' entries)
     // plus one state inside 256 VGPRs -- one pass up to D = 12, 2 / 3 / 4 passes for D = 14 / 16 / 18
     constexpr int JB = (D <= 12) ? D : (D == 14 ? 7 : (D == 16 ? 6 : 5));
+    constexpr int W = D + D * D;
     __shared__ double sh[(BLOCK / kWave) * (D + JB * D)];
-    MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, acc, bx, t0, t1, sh);
-    if (threadIdx.x == 0 && count_tile) {
-        const int64_t nr = min<int64_t>(BLOCK, n_roll - bx * BLOCK);
-        atomicAdd(&acc[0], (double)nr * (double)H);
+    __shared__ uint32_t ticket;
+    double *rows = acc + cov_sums(D) + 1;
+    MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1, sh);
+    __threadfence();   // this tile's row is visible device-wide before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0)
+        ticket = atomicAdd(reinterpret_cast<uint32_t *>(acc + cov_sums(D)), 1u);
+    __syncthreads();
+    if (ticket != n_tiles - 1u) return;
+    // last tile to finish: add every tile's row to acc, in tile order (four interleaved partial
+    // sums per entry, combined in a fixed tree)
+    __threadfence();
+    for (int j = threadIdx.x; j < W; j += BLOCK) {
+        const int f = (j - D) / D, g = (j - D) % D;
+        if (j >= D && g < f) continue;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        uint32_t t = 0;
+        for (; t + 4 <= n_tiles; t += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += rows[(int64_t)(t + q) * W + j];
+        }
+        for (int q = 0; t < n_tiles; ++t, ++q) a[q] += rows[(int64_t)t * W + j];
+        const double v = (a[0] + a[1]) + (a[2] + a[3]);
+        if (j < D) {
+            acc[1 + j] += v;
+        } else {   // mirror into both halves
+            acc[1 + D + f * D + g] += v;
+            if (g != f) acc[1 + D + g * D + f] += v;
+        }
+    }
+    if (threadIdx.x == 0) {
+        acc[0] += (double)n_roll * (double)H;
+        *reinterpret_cast<uint32_t *>(acc + cov_sums(D)) = 0u;   // ready for the next pass
     }
 }
 
-template <int D>
-__global__ void __launch_bounds__(kMomBlock)
+// standalone covariance pass: 1-D grid of nbx * ny tiles of BLOCK rollouts x tchunk steps
+template <int D, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 traj_moments_kernel(int64_t n_roll, int32_t H, const double *__restrict__ traj,
-                    double *__restrict__ acc)
+                    double *__restrict__ acc, uint32_t nbx, int32_t tchunk)
 {
-    const int32_t t0 = blockIdx.y * kMomTChunk;
-    moments_tile<D, kMomBlock>(n_roll, H, traj, acc, blockIdx.x, t0, min(H, t0 + kMomTChunk),
-                               blockIdx.y == 0);
+    const uint32_t bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const int32_t t0 = (int32_t)by * tchunk;
+    moments_tile<D, BLOCK>(n_roll, H, traj, acc, bx, t0, min(H, t0 + tchunk), blockIdx.x, gridDim.x);
 }
 
 // What a rollout launch of the ARS pipeline carries besides its rollouts (both optional):
@@ -493,6 +554,7 @@ struct SideJob {
     uint32_t flag_value;
     uint32_t first_cov_block;   // = number of rollout workgroups; UINT32_MAX: no covariance pass
     uint32_t cov_nbx;           // covariance tiles along the rollout axis
+    uint32_t cov_tiles;         // covariance tiles in all
     int32_t cov_tchunk;         // steps per covariance tile
     int32_t cov_H;
     int64_t cov_rolls;
@@ -507,7 +569,7 @@ __device__ __forceinline__ void side_cov_tile(const SideJob &sj)
     const uint32_t bx = b % sj.cov_nbx, by = b / sj.cov_nbx;
     const int32_t t0 = (int32_t)by * sj.cov_tchunk;
     moments_tile<D, BLOCK>(sj.cov_rolls, sj.cov_H, sj.cov_traj, sj.cov_acc, bx, t0,
-                           min(sj.cov_H, t0 + sj.cov_tchunk), by == 0);
+                           min(sj.cov_H, t0 + sj.cov_tchunk), b, sj.cov_tiles);
 }
 
 __device__ __forceinline__ void side_flag(const SideJob &sj)
@@ -1077,14 +1139,20 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
             if (e == 0 && sigma_out) *sigma_out = sigma;
         }
     } else if (running != nullptr) {
-        // V2: merge this iteration's partial sums into the running sums, then
-        // mean = c + S1/n, var = (S2 - S1^2/n)/(n-1) (np.cov, ddof = 1).
+        // V2 statistics over every state seen since training began (np.mean / np.cov with
+        // ddof = 1, ars_agent.py:179-182).  The reference recomputes them two-pass over the
+        // whole (ever-growing) list; here `running` = {n, mean - c, M2 = sum (x - mean)^2} and
+        // each iteration's batch is MERGED into it (Chan et al.): the batch's own mean and M2
+        // come from its sums about the pivot c (reset state; every rollout starts there, so
+        // |mean_b - c| is never large against the batch's spread), and the merge itself adds
+        // non-negative terms only -- no cancellation that grows with the length of training.
         // Thread (rg, j) = (tid / 64, tid % 64) sums column j over the rows whose GLOBAL index
         // (rank-major) is congruent to rg mod 4, in ascending order with eight loads in flight;
         // the four partial sums are combined in a fixed tree.  Global row indices make the
         // grouping -- and every bit of the result -- independent of the world size for
         // row-aligned shards, and identical on every rank.
         __shared__ double part[kUpdBlock / kWave][kWave];
+        __shared__ double bsum[kWave];
         const int j = threadIdx.x & 63, rg = threadIdx.x >> 6;
         const int32_t total = gv.world * gv.rows_chunk;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1102,20 +1170,26 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         }
         part[rg][j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
-        if (rg == 0 && j < 2 * d)
-            running[1 + j] += (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+        if (rg == 0) bsum[j] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
         __syncthreads();
-        if (threadIdx.x == 0) running[0] += n_new;
-        __syncthreads();
-        if (threadIdx.x < d) {
+        const double n0 = running[0], n1 = n0 + n_new;
+        if (threadIdx.x < d && n_new > 0.0) {
             const int c_ = threadIdx.x;
-            const double n = running[0];
-            const double s1 = running[1 + c_], s2 = running[1 + d + c_];
+            const double s1 = bsum[c_], s2 = bsum[d + c_];
+            const double mb = s1 / n_new;                       // batch mean - c
+            const double m2b = __builtin_fma(-s1, mb, s2);      // batch sum (x - mean_b)^2
+            const double mr = running[1 + c_], m2 = running[1 + d + c_];
+            const double delta = mb - mr;
+            const double mr1 = __builtin_fma(delta, n_new / n1, mr);
+            const double m21 = (m2 + m2b) + delta * delta * (n0 * (n_new / n1));
+            running[1 + c_] = mr1;
+            running[1 + d + c_] = m21;
             const double c = (c_ >= 2 && (c_ & 1) == 0) ? kHalfPi : 0.0;
-            mean[c_] = c + s1 / n;
-            const double var = (s2 - s1 * (s1 / n)) / (n - 1.0);
-            inv_std[c_] = 1.0 / sqrt(var);                   // diag(cov) ** -0.5
+            mean[c_] = c + mr1;
+            inv_std[c_] = 1.0 / sqrt(m21 / (n1 - 1.0));          // diag(cov) ** -0.5
         }
+        __syncthreads();
+        if (threadIdx.x == 0) running[0] = n1;
     }
 }
 
@@ -1208,7 +1282,7 @@ int launch_status()
     return hipGetLastError() == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
 }
 
-const SideJob kNoSide{nullptr, 0u, UINT32_MAX, 1u, 0, 0, 0, nullptr, nullptr};
+const SideJob kNoSide{nullptr, 0u, UINT32_MAX, 1u, 0u, 0, 0, 0, nullptr, nullptr};
 
 // Attach a covariance pass over (cov_traj, cov_rolls, cov_H) to a launch of `roll_blocks` rollout
 // workgroups of `block` threads; returns the number of extra workgroups.
@@ -1219,10 +1293,11 @@ unsigned side_attach_cov(SideJob &sj, unsigned roll_blocks, int block)
         sj.first_cov_block = UINT32_MAX;
         return 0;
     }
-    sj.cov_nbx = (uint32_t)((sj.cov_rolls + block - 1) / block);
-    sj.cov_tchunk = (block >= kMomBlock) ? kMomTChunk : kMomTChunk * (kMomBlock / block) / 2;
-    const unsigned ny = (unsigned)((sj.cov_H + sj.cov_tchunk - 1) / sj.cov_tchunk);
-    return sj.cov_nbx * ny;
+    const CovTiling t = cov_tiling(sj.cov_rolls, sj.cov_H, block);
+    sj.cov_nbx = t.nbx;
+    sj.cov_tchunk = t.tchunk;
+    sj.cov_tiles = t.nbx * t.ny;
+    return sj.cov_tiles;
 }
 
 }  // namespace
@@ -1479,19 +1554,48 @@ int sw_ars_update_gathered_f64(const sw_params *p, int64_t n_dir, const double *
                          mean, inv_std, sigma_out, stream);
 }
 
+// One covariance pass with workgroups of `block` (64 or 256) threads.  The pipeline runs the pass
+// it still owes with the block size of the rollout kernel that would have carried it, so a flushed
+// pass sums in exactly the order the ride-along pass would have (bit-identical resume).
+static int launch_traj_moments(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
+                               double *acc, int block, void *stream)
+{
+    if (n_roll < 0 || H < 0) return SW_ERR_SIZE;
+    if (n_roll == 0 || H == 0) return SW_OK;
+    if (!traj || !acc) return SW_ERR_NULL;
+    const CovTiling t = cov_tiling(n_roll, H, block);
+    const dim3 grid(t.nbx * t.ny);
+    if (block == kRollBlock) {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((traj_moments_kernel<2 * NN + 2, kRollBlock>), grid,
+                                               dim3(kRollBlock), 0, (hipStream_t)stream, n_roll, H,
+                                               traj, acc, t.nbx, t.tchunk));
+    } else {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((traj_moments_kernel<2 * NN + 2, kMomBlock>), grid,
+                                               dim3(kMomBlock), 0, (hipStream_t)stream, n_roll, H,
+                                               traj, acc, t.nbx, t.tchunk));
+    }
+    return launch_status();
+}
+
+int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H)
+{
+    if (check_params(p) != SW_OK || n_roll < 0 || H < 0) return -1;
+    const int d = 2 * p->n + 2;
+    int64_t tiles = 0;
+    if (n_roll > 0 && H > 0) {
+        const CovTiling a = cov_tiling(n_roll, H, kRollBlock), b = cov_tiling(n_roll, H, kMomBlock);
+        const int64_t ta = (int64_t)a.nbx * a.ny, tb = (int64_t)b.nbx * b.ny;
+        tiles = ta > tb ? ta : tb;
+    }
+    return cov_sums(d) + 1 + tiles * (d + d * d);
+}
+
 int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
                         double *acc, void *stream)
 {
     int rc = check_params(p);
     if (rc) return rc;
-    if (n_roll < 0 || H < 0) return SW_ERR_SIZE;
-    if (n_roll == 0 || H == 0) return SW_OK;
-    if (!traj || !acc) return SW_ERR_NULL;
-    const dim3 grid((unsigned)((n_roll + kMomBlock - 1) / kMomBlock),
-                    (unsigned)((H + kMomTChunk - 1) / kMomTChunk));
-    SW_DISPATCH_N(p->n, hipLaunchKernelGGL(traj_moments_kernel<2 * NN + 2>, grid, dim3(kMomBlock), 0,
-                                           (hipStream_t)stream, n_roll, H, traj, acc));
-    return launch_status();
+    return launch_traj_moments(p, n_roll, H, traj, acc, kMomBlock, stream);
 }
 
 // ---- ARS iteration pipeline ---------------------------------------------------------
@@ -1528,6 +1632,7 @@ struct sw_ars_pipeline {
     double *cov_acc = nullptr;
     int64_t cov_rolls = 0;
     int32_t cov_H = 0;
+    int cov_block = 0;                                     // workgroup size the pass is run with
     sw_params cov_params = {};
 };
 
@@ -1557,8 +1662,8 @@ int wait_flag(const sw_ars_pipeline *pl, uint32_t need)
 int flush_owed_cov(sw_ars_pipeline *pl, hipStream_t stream)
 {
     if (!pl->cov_traj) return SW_OK;
-    const int rc = sw_traj_moments_f64(&pl->cov_params, pl->cov_rolls, pl->cov_H, pl->cov_traj,
-                                       pl->cov_acc, stream);
+    const int rc = launch_traj_moments(&pl->cov_params, pl->cov_rolls, pl->cov_H, pl->cov_traj,
+                                       pl->cov_acc, pl->cov_block, stream);
     pl->cov_traj = nullptr;
     return rc;
 }
@@ -1656,6 +1761,11 @@ int sw_ars_pipeline_rollout_ms(sw_ars_pipeline *pl, double *mean_ms, int64_t *la
     return SW_OK;
 }
 
+int sw_ars_pipeline_next_slot(sw_ars_pipeline *pl)
+{
+    return pl ? (int)(pl->launches % (uint32_t)SW_PIPELINE_SLOTS) : -1;
+}
+
 int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params *p,
                                   int64_t n_dir_total, int64_t dir_begin, int64_t n_dir, int32_t H,
                                   const double *deltas_host, double *deltas_dev,
@@ -1666,7 +1776,12 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
     int rc = check_params(p);
     if (rc) return rc;
     if (!pl || !deltas_host || !deltas_dev) return SW_ERR_NULL;
-    if (slot < 0 || slot >= SW_PIPELINE_SLOTS || n_dir_total < dir_begin + n_dir) return SW_ERR_SIZE;
+    if (n_dir < 0 || dir_begin < 0 || H < 0 || n_dir_total < dir_begin + n_dir) return SW_ERR_SIZE;
+    // The slot is a function of the pipeline's own call count, never of the caller's bookkeeping:
+    // call k uses slot k mod SLOTS, and every call counts -- also a rank's call with an empty
+    // shard (world > N), which launches nothing but the progress flag.
+    const uint32_t k = pl->launches;
+    if (slot != (int)(k % (uint32_t)SW_PIPELINE_SLOTS)) return SW_ERR_SIZE;
     if (cov_acc && !traj && n_dir > 0) return SW_ERR_NULL;
     hipStream_t main = (hipStream_t)stream;
     if (pl->main_seen && pl->last_main != main) {
@@ -1676,11 +1791,10 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
     pl->last_main = main;
     pl->main_seen = true;
     const size_t bytes = (size_t)n_dir_total * (size_t)((p->n - 1) * (2 * p->n + 2)) * sizeof(double);
-    // Launch k reuses the buffers of launch k - SLOTS: its device deltas were last read by update
+    // Call k reuses the buffers of call k - SLOTS: its device deltas were last read by update
     // k - SLOTS (done once launch k - SLOTS + 1 has started) and its trajectories by the
     // covariance workgroups of launch k - SLOTS + 1 (done once launch k - SLOTS + 2 has started).
-    const uint32_t k = pl->launches;
-    if (k >= (uint32_t)SW_PIPELINE_SLOTS && n_dir > 0) {
+    if (k >= (uint32_t)SW_PIPELINE_SLOTS) {
         rc = wait_flag(pl, k + 2u - (uint32_t)SW_PIPELINE_SLOTS);
         if (rc) return rc;
     }
@@ -1690,54 +1804,63 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
     pl->h2d_valid[slot] = true;
     // host-confirmed: the deltas have landed -> the rollout launch needs no device-side wait
     if (hipEventSynchronize(pl->h2d_done[slot]) != hipSuccess) return SW_ERR_LAUNCH;
-    if (n_dir > 0) {
-        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-        const bool timed_launch = pl->timing > 0 && (pl->timing_launches++ % pl->timing) == 0;
-        if (timed_launch) {
-            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess ||
-                hipEventRecord(ev.first, main) != hipSuccess)
-                return SW_ERR_LAUNCH;
-        }
-        SideJob sj = kNoSide;
-        sj.flag = pl->flag_dev;
-        sj.flag_value = k;
+    if (n_dir == 0) {
+        // empty shard: keep the flag sequence going (the host paces the ring on it)
+        hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, main, pl->flag_dev, k);
+        rc = launch_status();
+        if (rc) return rc;
+        pl->launches = k + 1u;
+        return SW_OK;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed_launch = pl->timing > 0 && (pl->timing_launches++ % pl->timing) == 0;
+    if (timed_launch) {
+        if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess ||
+            hipEventRecord(ev.first, main) != hipSuccess)
+            return SW_ERR_LAUNCH;
+    }
+    const bool quad = use_quad3(p, 2 * n_dir, H, traj != nullptr);
+    const bool row = !quad && use_row(p, 2 * n_dir, H, traj != nullptr);
+    const int block = quad ? kRollBlock : kMomBlock;   // kRowBlock == kMomBlock
+    SideJob sj = kNoSide;
+    sj.flag = pl->flag_dev;
+    sj.flag_value = k;
+    // the owed pass rides along when this launch's kernel can carry it in the tiling it is owed in
+    const bool ride = pl->cov_traj && (quad || row) && pl->cov_params.n == p->n &&
+                      pl->cov_block == block;
+    if (pl->cov_traj && !ride) {
+        rc = flush_owed_cov(pl, main);
+        if (rc) return rc;
+    }
+    if (ride) {
         sj.cov_traj = pl->cov_traj;
         sj.cov_acc = pl->cov_acc;
         sj.cov_rolls = pl->cov_rolls;
         sj.cov_H = pl->cov_H;
-        const bool cov_dims_match = pl->cov_traj && pl->cov_params.n == p->n;
-        if (!cov_dims_match) sj.cov_traj = nullptr;
-        bool taken = false;
-        if (!use_quad3(p, 2 * n_dir, H, traj != nullptr) && !use_row(p, 2 * n_dir, H, traj != nullptr)) {
-            // the lane kernel takes no side job: flag and owed covariance pass as launches of
-            // their own in front of it (not the fast path)
-            hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, main, pl->flag_dev, k);
-            rc = flush_owed_cov(pl, main);
-            if (rc) return rc;
-            sj = kNoSide;
-        } else if (pl->cov_traj && !cov_dims_match) {
-            rc = flush_owed_cov(pl, main);
-            if (rc) return rc;
-        }
-        rc = launch_ars_rollouts(p, dir_begin, n_dir, H, policy, deltas_dev, nu, mean, inv_std,
-                                 returns, traj, moments, status, stream, &sj, &taken);
-        if (timed_launch) {
-            (void)hipEventRecord(ev.second, main);
-            pl->timed.push_back(ev);
-        }
-        if (rc) return rc;
-        if (taken && sj.cov_traj) pl->cov_traj = nullptr;   // rides along in this launch
-        pl->launches = k + 1u;
-        // this launch's trajectories are owed a covariance pass: the next launch carries it
-        if (cov_acc) {
-            rc = flush_owed_cov(pl, main);   // normally nothing left
-            if (rc) return rc;
-            pl->cov_traj = traj;
-            pl->cov_acc = cov_acc;
-            pl->cov_rolls = 2 * n_dir;
-            pl->cov_H = H;
-            pl->cov_params = *p;
-        }
+    }
+    bool taken = false;
+    if (!quad && !row) {
+        // the lane kernel takes no side job: the flag as a launch of its own in front of it
+        hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, main, pl->flag_dev, k);
+        sj = kNoSide;
+    }
+    rc = launch_ars_rollouts(p, dir_begin, n_dir, H, policy, deltas_dev, nu, mean, inv_std,
+                             returns, traj, moments, status, stream, &sj, &taken);
+    if (timed_launch) {
+        (void)hipEventRecord(ev.second, main);
+        pl->timed.push_back(ev);
+    }
+    if (rc) return rc;
+    if (ride) pl->cov_traj = nullptr;   // rode along in this launch
+    pl->launches = k + 1u;
+    // this launch's trajectories are owed a covariance pass: the next launch carries it
+    if (cov_acc) {
+        pl->cov_traj = traj;
+        pl->cov_acc = cov_acc;
+        pl->cov_rolls = 2 * n_dir;
+        pl->cov_H = H;
+        pl->cov_block = block;
+        pl->cov_params = *p;
     }
     return SW_OK;
 }

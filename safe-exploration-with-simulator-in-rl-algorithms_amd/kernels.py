@@ -164,14 +164,54 @@ def ars_update(p: SwParams, returns, deltas, policy, alpha: float, b: float, top
     return policy
 
 
+def ars_update_gathered(p: SwParams, n_dir: int, gathered, world: int, chunk: int, rows_chunk: int,
+                        deltas, policy, alpha: float, b: float, top_b: int = 0, running=None,
+                        n_new_states: int = 0, mean=None, inv_std=None, sigma_out=None):
+    """The ARS update reading the all-gathered result segments in place: `gathered` holds
+    `world` segments [2*chunk returns | rows_chunk moment rows of 2d] (sw_ars_update_gathered_f64)."""
+    require_gpu()
+    seg = 2 * chunk + rows_chunk * 2 * p.d
+    _want(gathered, "gathered", (world * seg,))
+    _want(policy, "policy", (p.m, p.d))
+    _want(deltas, "deltas", (deltas.shape[0], p.m, p.d))
+    if deltas.shape[0] < n_dir:
+        raise _lib.SwimmerHipError("deltas: fewer directions than n_dir")
+    if running is not None:
+        _want(running, "running", (1 + 2 * p.d,))
+        _want(mean, "mean", (p.d,))
+        _want(inv_std, "inv_std", (p.d,))
+    check(load().sw_ars_update_gathered_f64(
+        ctypes.byref(p), int(n_dir), ptr(gathered), int(world), int(chunk), int(rows_chunk),
+        ptr(deltas), ptr(policy), float(alpha), float(b), int(top_b), ptr(running),
+        int(n_new_states), ptr(mean), ptr(inv_std), ptr(sigma_out), stream_ptr()),
+        "sw_ars_update_gathered_f64")
+    return policy
+
+
+def cov_acc_doubles(p: SwParams, n_roll: int, H: int) -> int:
+    """Doubles in the accumulator of a covariance pass over (n_roll, H): the 1 + d + d*d sums
+    followed by the pass's scratch (include/swimmer_hip.h)."""
+    n = int(load().sw_cov_acc_doubles(ctypes.byref(p), int(n_roll), int(H)))
+    if n < 0:
+        raise _lib.SwimmerHipError("sw_cov_acc_doubles: bad arguments")
+    return n
+
+
+def new_cov_acc(p: SwParams, n_roll: int, H: int, device):
+    return torch.zeros(cov_acc_doubles(p, n_roll, H), dtype=torch.float64, device=device)
+
+
 def traj_moments(p: SwParams, traj, acc=None):
-    """acc [1 + d + d*d] += {count, sum(s-c), sum((s-c)(s-c)^T)} over traj [H, d, n_roll]."""
+    """acc[:1 + d + d*d] += {count, sum(s-c), sum((s-c)(s-c)^T)} over traj [H, d, n_roll];
+    acc = new_cov_acc(p, n_roll, H, device) (sums + scratch), reusable for further passes of
+    the same shape.  Deterministic (no floating-point atomics)."""
     require_gpu()
     H, d, n_roll = traj.shape
     _want(traj, "traj", (H, p.d, n_roll))
     if acc is None:
-        acc = torch.zeros(1 + d + d * d, dtype=torch.float64, device=traj.device)
-    _want(acc, "acc", (1 + d + d * d,))
+        acc = new_cov_acc(p, n_roll, H, traj.device)
+    if acc.dtype != torch.float64 or acc.dim() != 1 or acc.numel() < cov_acc_doubles(p, n_roll, H):
+        raise _lib.SwimmerHipError("acc: need a float64 vector of cov_acc_doubles(p, n_roll, H)")
     check(load().sw_traj_moments_f64(ctypes.byref(p), n_roll, H, ptr(traj), ptr(acc),
                                      stream_ptr()), "sw_traj_moments_f64")
     return acc
@@ -199,6 +239,10 @@ class ArsPipeline(object):
             self.close()
         except Exception:
             pass
+
+    def next_slot(self):
+        """Ring slot of the next rollouts() call (the pipeline's own call count mod slots)."""
+        return int(load().sw_ars_pipeline_next_slot(self._h))
 
     def host_slot_wait(self, slot):
         check(load().sw_ars_pipeline_host_slot_wait(self._h, slot), "sw_ars_pipeline_host_slot_wait")

@@ -42,14 +42,17 @@ int main(int argc, char **argv)
     CHECK_HIP(hipMalloc((void **)&mean, sizeof(double) * d));
     CHECK_HIP(hipMalloc((void **)&inv_std, sizeof(double) * d));
     CHECK_HIP(hipMalloc((void **)&running, sizeof(double) * (1 + 2 * d)));
-    CHECK_HIP(hipMalloc((void **)&cov_acc, sizeof(double) * ncov));
+    /* the covariance accumulator carries the pass's scratch behind the 1 + d + d d sums */
+    const int64_t cov_len = sw_cov_acc_doubles(&p, 2 * N, H);
+    if (cov_len < (int64_t)ncov) return 1;
+    CHECK_HIP(hipMalloc((void **)&cov_acc, sizeof(double) * (size_t)cov_len));
     CHECK_HIP(hipMalloc((void **)&sigma, sizeof(double)));
     CHECK_HIP(hipMalloc((void **)&send, sizeof(double) * seg));
     CHECK_HIP(hipMalloc((void **)&status, sizeof(int32_t) * 2 * N));
     CHECK_HIP(hipMemset(policy, 0, sizeof(double) * md));        /* initial_w = 'Zero' */
     CHECK_HIP(hipMemset(mean, 0, sizeof(double) * d));           /* first V2 iteration: mean 0, cov I */
     CHECK_HIP(hipMemset(running, 0, sizeof(double) * (1 + 2 * d)));
-    CHECK_HIP(hipMemset(cov_acc, 0, sizeof(double) * ncov));
+    CHECK_HIP(hipMemset(cov_acc, 0, sizeof(double) * (size_t)cov_len));
     CHECK_HIP(hipMemset(send, 0, sizeof(double) * seg));
     CHECK_HIP(hipMemset(status, 0, sizeof(int32_t) * 2 * N));
     double ones[8] = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -58,7 +61,7 @@ int main(int argc, char **argv)
     sw_ars_pipeline *pl;
     CHECK_SW(sw_ars_pipeline_create(&pl));
     for (int it = 0; it < iters; ++it) {
-        const int s = it % SW_PIPELINE_SLOTS;
+        const int s = sw_ars_pipeline_next_slot(pl);   /* the pipeline's own call count mod slots */
         CHECK_SW(sw_ars_pipeline_host_slot_wait(pl, s));
         memcpy(dh[s], all + per_iter * it, sizeof(double) * per_iter);
         CHECK_SW(sw_ars_iteration_rollouts_f64(pl, s, &p, N, 0, N, H, dh[s], dd[s], policy, nu, mean, inv_std,

@@ -270,7 +270,112 @@ def gen_ars():
     print("ars.npz", len(out))
 
 
+def gen_mirrors():
+    """Public methods of the reference classes that the ARS loop does not exercise in the form a
+    user may call them: Environment.select_action (V1 and V2, ars/environment.py:19-35),
+    ARSAgent.update_policy with an `order` that is a SUBSET in non-sorted order
+    (ars_agent.py:110-130), and the initial_w=<file>.npy warm start (ars_agent.py:74-81)."""
+    out = {}
+    rs = np.random.RandomState(11)
+    for n in (3, 6):
+        d, m = 2 * n + 2, n - 1
+        ep = EnvParam("LeonSwimmer-Golden", n=n, H=10, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+        renv = Environment(ep)
+        P = rs.uniform(-1, 1, (m, d))
+        obs = rs.uniform(-2, 2, (5, d))
+        mean = 0.3 * rs.randn(d)
+        A = rs.randn(d, d)
+        cov = 0.05 * A @ A.T + np.diag(rs.uniform(1e-6, 2.0, d))
+        out[f"sel_n{n}_policy"], out[f"sel_n{n}_obs"] = P, obs
+        out[f"sel_n{n}_mean"], out[f"sel_n{n}_cov"] = mean, cov
+        out[f"sel_n{n}_v1"] = np.array([renv.select_action(P, o.tolist()) for o in obs])
+        out[f"sel_n{n}_v2"] = np.array([renv.select_action(P, o.tolist(), cov, mean) for o in obs])
+
+    # update_policy(deltas, rewards, order): order = 3 of 7 directions, not sorted
+    n, N = 3, 7
+    d, m = 2 * n + 2, n - 1
+    ep = EnvParam("LeonSwimmer-Golden", n=n, H=10, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = ARSParam("Golden", V1=True, n_iter=1, H=10, N=N, b=3, alpha=0.02, nu=0.01,
+                  safe=False, threshold=0, initial_w="Zero")
+    agent = ARSAgent(ep, ap, seed=0)
+    P0 = rs.uniform(-0.5, 0.5, (m, d))
+    deltas = [2 * rs.rand(m, d) - 1 for _ in range(N)]
+    rewards = rs.uniform(-3, 8, 2 * N).tolist()
+    order = [5, 0, 3]
+    agent.policy = P0.copy()
+    agent.update_policy(deltas, rewards, order)
+    out["upd_policy0"], out["upd_deltas"], out["upd_rewards"] = P0, np.array(deltas), np.array(rewards)
+    out["upd_order"] = np.array(order, dtype=np.int64)
+    out["upd_alpha_b"] = np.array([ap.alpha, ap.b])
+    out["upd_policy1"] = np.array(agent.policy)
+    out["upd_sorted"] = np.array(agent.sort_directions(deltas, rewards), dtype=np.int64)
+
+    # warm start from a saved policy file (the caller writes W0 to an .npy first)
+    import tempfile
+    W0 = 0.05 * (2 * rs.rand(m, d) - 1)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "w0.npy")
+        np.save(path, W0)
+        ep = EnvParam("LeonSwimmer-Golden", n=3, H=80, l_i=0.8, m_i=1.2, h=1e-3, k=10.2, epsilon=0)
+        ap = ARSParam("Golden", V1=False, n_iter=2, H=80, N=4, b=4, alpha=0.0075, nu=0.01,
+                      safe=False, threshold=0, initial_w=path)
+        agent = ARSAgent(ep, ap, seed=8)
+        assert np.array_equal(agent.policy, W0)
+        rewards = np.empty((2, 8))
+        pols = np.empty((2, m, d))
+        for it in range(2):
+            with contextlib.redirect_stdout(io.StringIO()):
+                rewards[it] = agent.runOneIteration()
+            pols[it] = agent.policy
+    out["warm_w0"], out["warm_rewards"], out["warm_policies"] = W0, rewards, pols
+    out["warm_mean"], out["warm_cov"] = np.array(agent.mean), np.array(agent.covariance)
+    np.savez_compressed(os.path.join(OUT, "mirrors.npz"), **out)
+    print("mirrors.npz", len(out))
+
+
+def gen_long():
+    """A reference run that actually LEARNS, so the V2 statistics move away from the reset
+    state (hard part 1): n = 3, "realworld" parameters, N = 8, H = 200,
+    60 iterations; checkpoints of policy / mean / diag(cov) / returns every 10 iterations."""
+    out = {}
+    n, N, H, iters, every = 3, 8, 200, 60, 10
+    l_i, m_i, k, h = PARAM_SETS["realworld"]
+    alpha, nu, seed = 0.02, 0.03, 4
+    ep = EnvParam("LeonSwimmer-Golden", n=n, H=H, l_i=l_i, m_i=m_i, h=h, k=k, epsilon=0)
+    ap = ARSParam("Golden", V1=False, n_iter=iters, H=H, N=N, b=N, alpha=alpha, nu=nu,
+                  safe=False, threshold=0, initial_w="Zero")
+    agent = ARSAgent(ep, ap, seed=seed)
+    d, m = 2 * n + 2, n - 1
+    curve = np.empty(iters)
+    keep = list(range(every - 1, iters, every))
+    rewards = np.empty((len(keep), 2 * N))
+    pols = np.empty((len(keep), m, d))
+    means = np.empty((len(keep), d))
+    dcov = np.empty((len(keep), d))
+    for it in range(iters):
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = agent.runOneIteration()
+        curve[it] = np.mean(r)
+        if it in keep:
+            j = keep.index(it)
+            rewards[j], pols[j] = r, agent.policy
+            means[j], dcov[j] = agent.mean, np.diag(agent.covariance)
+    out["long_cfg"] = np.array([n, N, H, iters, every, seed], dtype=np.int64)
+    out["long_phys"] = np.array([l_i, m_i, k, h, alpha, nu])
+    out["long_curve"], out["long_rewards"], out["long_policies"] = curve, rewards, pols
+    out["long_means"], out["long_diag_covs"] = means, dcov
+    out["long_full_cov_last"] = np.array(agent.covariance)
+    np.savez_compressed(os.path.join(OUT, "long.npz"), **out)
+    print("long.npz: mean return first / last", curve[0], curve[-1], "max", curve.max())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # e.g. `make_golden.py mirrors long`: only these files
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
+    gen_mirrors()
+    gen_long()
     gen_kat()
     gen_steps()
     gen_trajectories()

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(sw):
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/swimmer_hip.h but not exported"
     assert set(sw._lib.EXPORTED_SYMBOLS) == set(declared_functions())
-    assert sw._lib.load().sw_abi_version() == 1
+    assert sw._lib.load().sw_abi_version() == 2
     assert sw._lib.load().sw_max_segments() == 8
 
 

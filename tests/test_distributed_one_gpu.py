@@ -37,7 +37,7 @@ def _worker(rank, world, port, N, H, out):
         import swimmer_amd as sw
         agent = _make_agent(sw, N, H, False, 11)
         rets = [agent.runOneIteration() for _ in range(3)]
-        out.put((rank, np.array(rets), agent.policy, agent.mean, agent.covariance,
+        out.put((rank, np.array(rets), agent.policy, agent.mean, agent.reduce_covariance(),
                  (agent.lo, agent.hi)))
     finally:
         dist.destroy_process_group()

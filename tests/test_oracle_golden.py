@@ -1,12 +1,14 @@
 """Pins the CPU oracle (oracle/) to the reference: every function is compared with the
 outputs the reference itself produced (tests/golden/*.npz, see make_golden.py) and with the
 reference-authored known answer rlglue/test/acceleration-compare.txt:5-6."""
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 from oracle.ars_oracle import ArsOracle
-from conftest import PARAM_SETS
+from conftest import GOLDEN, PARAM_SETS
 
 STEP_TOL = 2e-15      # observed <= 4.5e-16 (94-99 % of the doubles bit-identical)
 TRAJ_TOL = 1e-11      # observed <= 2e-13 over 1000 steps
@@ -108,3 +110,36 @@ def test_ars_training_curve(golden):
     curve = o.training(4)
     assert np.abs(curve - a["train_v2_n3_N3_H60_curve"]).max() < 1e-15   # returns are ~1e-12
     assert np.abs(o.policy - a["train_v2_n3_N3_H60_policy"]).max() < 1e-7  # short-H amplification
+
+
+def _coulom_records():
+    import json
+    with open(os.path.join(GOLDEN, "twin_kat.json")) as f:
+        return json.load(f)["coulom"]
+
+
+def coulom_consistency(accel, rec):
+    """Coulom's program printed, for a state, the barycentre acceleration and the three angle
+    accelerations, but not the joint torques it used.  G-double-dot does not depend on the
+    torques; theta-double-dot is affine in them, so the recorded vector must be reachable:
+    exists u (2 unknowns) with thdd(u) = recorded (3 equations).  Returns (|dGx|, u, residual)."""
+    st = np.array(rec["state"])
+    g0, t0 = accel(st, [0.0, 0.0])
+    J = np.stack([accel(st, e)[1] - t0 for e in ([1.0, 0.0], [0.0, 1.0])], axis=1)
+    want = np.array(rec["angle_accelerations"])
+    u, *_ = np.linalg.lstsq(J, want - t0, rcond=None)
+    res = np.abs(t0 + J @ u - want).max()
+    return abs(g0[0] - rec["barycenter_acceleration"][0]), abs(g0[1]), u, res
+
+
+def test_oracle_vs_both_states_of_coulom_program():
+    """rlglue/test/acceleration-compare.txt:4-12 -- the only numbers in the reference repository
+    that come from OUTSIDE its own code (Coulom's original swimmer), printed to 6 digits for
+    states printed to 6 digits.  The Gym model (and so the oracle) reproduces them."""
+    p = oracle.OracleParams.make(3)
+    for rec, gx_tol in zip(_coulom_records(), (1e-6, 2e-5)):
+        dgx, gy, u, res = coulom_consistency(lambda s, a: oracle.accelerations(p, s, a), rec)
+        assert dgx < gx_tol          # state 2: 0.282799 from the 6-digit state vs 0.282794 printed
+        assert gy < 1e-5             # recorded -8e-11; 1.5708 is not exactly pi / 2
+        assert res < 1e-5            # the recorded angle accelerations are consistent (3 eq., 2 unknowns)
+        assert np.abs(u - u[0]).max() < 1e-3 and 0.0 < u[0] < 0.1   # a small symmetric torque

@@ -1,0 +1,198 @@
+"""Protocol of the native ARS pipeline and of the agent around it (round-2 findings):
+ring slot owned by the pipeline, ranks with an empty shard, checkpoints loaded into an agent
+that has already run, trajectory recording on the asynchronous path, stale HIP errors."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sw():
+    import swimmer_amd
+    return swimmer_amd
+
+
+def _agent(sw, N=6, H=120, seed=9, n=3, **kw):
+    ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=0.8, m_i=1.2, h=1e-3, k=10.2, epsilon=0)
+    ap = sw.ARSParam("Test", V1=False, n_iter=4, H=H, N=N, b=N, alpha=0.0075, nu=0.01,
+                     safe=False, threshold=0, initial_w="Zero")
+    return sw.ARSAgent(ep, ap, seed=seed, device="cuda:0", **kw)
+
+
+def test_slot_is_the_pipelines_own_count(sw):
+    a = _agent(sw)
+    pipe = a._pipe
+    assert pipe.next_slot() == 0
+    for k in range(6):                       # more iterations than slots
+        assert pipe.next_slot() == k % pipe.slots
+        a.run_iteration_async(want_returns=False)
+    a._it = 0                                # the agent's counter no longer matters
+    assert pipe.next_slot() == 6 % pipe.slots
+    # a call with any other slot is refused, nothing is launched, the count stays
+    wrong = (pipe.next_slot() + 1) % pipe.slots
+    ap = a.agent_param
+    with pytest.raises(sw.SwimmerHipError, match="SW_ERR_SIZE"):
+        pipe.rollouts(wrong, a.params, ap.N, a.lo, a.n_local, ap.H, a._deltas_host[wrong],
+                      a._deltas2[wrong], a._policy, ap.nu, a._mean, a._inv_std, a._returns_local,
+                      a._traj2[wrong], a._moments_local, a._cov_acc, a._status)
+    assert pipe.next_slot() == 6 % pipe.slots
+    a.runOneIteration()
+    torch.cuda.synchronize()
+
+
+def test_checkpoint_loaded_into_an_agent_that_has_run(sw, tmp_path):
+    """load_checkpoint on a used agent: the ring phase is the pipeline's, every queued kernel is
+    drained first, and the continuation is bit-identical to the uninterrupted run."""
+    a = _agent(sw, seed=9)
+    for _ in range(2):
+        a.runOneIteration()
+    a.save_checkpoint(str(tmp_path / "ck.npz"))
+    tail_a = [a.runOneIteration() for _ in range(3)]
+    b = _agent(sw, seed=77)
+    for _ in range(3):                       # 3 iterations: its ring phase differs from a's
+        b.run_iteration_async(want_returns=False)
+    b.load_checkpoint(str(tmp_path / "ck.npz"))      # no synchronisation by the caller
+    tail_b = [b.runOneIteration() for _ in range(3)]
+    assert np.array_equal(np.array(tail_a), np.array(tail_b))
+    assert np.array_equal(a.policy, b.policy) and np.array_equal(a.mean, b.mean)
+    assert np.array_equal(a.covariance, b.covariance)
+    # the same agent again, now with iterations in flight
+    for _ in range(5):
+        b.run_iteration_async(want_returns=False)
+    b.load_checkpoint(str(tmp_path / "ck.npz"))
+    tail_c = [b.runOneIteration() for _ in range(3)]
+    assert np.array_equal(np.array(tail_a), np.array(tail_c))
+    assert np.array_equal(a.covariance, b.covariance)
+
+
+def test_round1_checkpoint_format_is_converted(sw, tmp_path):
+    """Files written before the statistics became {n, mean - c, M2} hold raw sums."""
+    a = _agent(sw, seed=5)
+    for _ in range(2):
+        a.runOneIteration()
+    a.save_checkpoint(str(tmp_path / "new.npz"))
+    z = dict(np.load(tmp_path / "new.npz"))
+    d = a.d
+    n, mr, m2 = z["running"][0], z["running"][1:1 + d], z["running"][1 + d:]
+    old = dict(z)
+    old.pop("format")
+    old["running"] = np.concatenate(([n], mr * n, m2 + (mr * n) * mr))    # raw S1, S2 about c
+    np.savez(tmp_path / "old.npz", **old)
+    b = _agent(sw, seed=1)
+    b.load_checkpoint(str(tmp_path / "old.npz"))
+    got = b._running.cpu().numpy()
+    assert got[0] == n and np.allclose(got[1:1 + d], mr, rtol=1e-14, atol=0)
+    assert np.allclose(got[1 + d:], m2, rtol=1e-9, atol=0)
+
+
+def test_async_iterations_record_matching_policies(sw):
+    """run_iteration_async(record_trajectories=True) without runOneIteration: the stored
+    policy of rollout 2i / 2i+1 is P_before_update +/- nu * delta_i, and replaying it
+    reproduces the stored trajectory."""
+    a = _agent(sw, N=4, H=60, seed=3, record_trajectories=True)
+    nu = a.agent_param.nu
+    pre, deltas = [], []
+    rng = np.random.RandomState(3)            # the stream the agent draws from
+    for _ in range(3):
+        pre.append(a.policy.copy())
+        deltas.append(2 * rng.rand(4, a.m, a.d) - 1)
+        a.run_iteration_async(want_returns=False)
+    torch.cuda.synchronize()
+    pols = np.array(a.database.policies)
+    trajs = np.array(a.database.trajectories)
+    assert pols.shape == (3 * 8, a.m, a.d) and trajs.shape == (3 * 8, 60, a.d)
+    for it in range(3):
+        for i in range(4):
+            assert np.array_equal(pols[it * 8 + 2 * i], pre[it] + nu * deltas[it][i])
+            assert np.array_equal(pols[it * 8 + 2 * i + 1], pre[it] - nu * deltas[it][i])
+    assert not np.array_equal(pre[0], pre[2])            # the policy did move in between
+    # first iteration ran with mean 0 / cov I: replay two of its stored policies
+    env = sw.Environment(a.real_env_param)
+    for r in (0, 5):
+        _, states = env.rollout(pols[r])
+        assert np.abs(np.array(states) - trajs[r]).max() <= 1e-12
+
+
+def _loaded_hip_runtime():
+    """The libamdhip64 this process already has mapped (torch's), not a second copy."""
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                return ctypes.CDLL(line.split()[-1])
+    raise RuntimeError("no HIP runtime mapped")
+
+
+def test_a_stale_hip_error_is_not_blamed_on_our_launch(sw):
+    p = sw.SwParams.make(3)
+    sw.kernels.reset(p, 8)
+    hip = _loaded_hip_runtime()
+    assert hip.hipSetDevice(9999) != 0                 # a failed call of "somebody else"
+    st = sw.kernels.reset(p, 16)                       # must not report SW_ERR_LAUNCH
+    assert st.shape == (8, 16)
+    torch.cuda.synchronize()
+
+
+# ---- ranks with an empty shard (world > N) ------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, H, iters, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import swimmer_amd as sw
+        a = _agent(sw, N=N, H=H, seed=11)
+        rets = [a.runOneIteration() for _ in range(iters)]
+        cov = a.reduce_covariance()
+        pol, mean = a.policy, a.mean
+        try:
+            a.run_iteration_async(want_returns=False)
+            a.covariance
+            raised = False
+        except sw.SwimmerHipError:
+            raised = True
+        out.put((rank, np.array(rets), pol, mean, cov, a.n_local, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_directions(sw):
+    """world = 3, N = 2: rank 2 owns no direction.  It must keep pace with the ring (its H2D of
+    the deltas may not overtake the update that still reads the slot) for more iterations than
+    the ring has slots, and end with the same policy as everybody else."""
+    N, H, world, iters = 2, 100, 3, 7
+    ref = _agent(sw, N=N, H=H, seed=11)
+    ref_rets = np.array([ref.runOneIteration() for _ in range(iters)])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, H, iters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    assert [r[5] for r in res] == [1, 1, 0]
+    sd = np.sqrt(np.diag(ref.covariance))
+    for rank, rets, pol, mean, cov, _, raised in res:
+        assert np.array_equal(rets[0], ref_rets[0]), rank
+        assert np.allclose(rets, ref_rets, rtol=1e-5, atol=1e-20), rank
+        assert np.abs(pol - ref.policy).max() < 1e-8
+        assert np.array_equal(pol, res[0][2])               # identical on every rank
+        assert (np.abs(cov - ref.covariance) <= 1e-9 * np.outer(sd, sd)).all()
+        assert raised      # reading `covariance` after a further iteration without the collective

@@ -96,7 +96,7 @@ def _seg_worker(rank, world, port, n_dir, width, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_dir", [(2, 64), (2, 9), (3, 20)])
+@pytest.mark.parametrize("world,n_dir", [(2, 64), (2, 9), (3, 20), (8, 2048)])   # last: configs[3] / [4]
 def test_packed_segments_over_gloo(world, n_dir):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
