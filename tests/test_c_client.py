@@ -75,7 +75,10 @@ def test_plain_c_ars_pipeline(tmp_path):
     ref_inv = np.diag(ref.covariance) ** -0.5
     rel = np.abs(inv_std / ref_inv - 1.0).max()
     print(f"inv_std: max relative deviation {rel:.3e}")
-    assert rel <= 1e-7    # one-pass pivoted sums on the device vs np.cov's two passes: observed 4e-9
+    # observed 3.8e-9: trajectory differences of ~1e-14 on coordinates whose variance is ~1e-24
+    # (Gdot_x of these nearly symmetric rollouts), NOT the statistics algorithm -- that one is
+    # bounded at 1e-15 by tests/test_mirrors_and_statistics.py on the device's own states
+    assert rel <= 1e-7
     cnt, s1, s2 = acc[0], acc[1:1 + d], acc[1 + d:].reshape(d, d)
     assert cnt == iters * 2 * N * H
     cov = (s2 - np.outer(s1, s1) / cnt) / (cnt - 1.0)
