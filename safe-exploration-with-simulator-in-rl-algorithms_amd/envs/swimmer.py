@@ -88,7 +88,9 @@ class VecSwimmerEnv(object):
         if self._next is None:
             self._next = torch.empty_like(self.state)
             self._reward = torch.empty(self.n_env, dtype=torch.float64, device=self.device)
-        key = (self.state.data_ptr(), a.data_ptr(), self._next.data_ptr())
+        # a plan pins the stream that was current when it was made: the stream is part of the key
+        key = (self.state.data_ptr(), a.data_ptr(), self._next.data_ptr(),
+               torch.cuda.current_stream(self.device).cuda_stream)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 8:

@@ -196,3 +196,89 @@ def test_more_ranks_than_directions(sw):
         assert np.array_equal(pol, res[0][2])               # identical on every rank
         assert (np.abs(cov - ref.covariance) <= 1e-9 * np.outer(sd, sd)).all()
         assert raised      # reading `covariance` after a further iteration without the collective
+
+
+def test_vec_env_plans_are_per_stream(sw):
+    """A pre-bound step launch pins the stream it was made under; stepping the same env under
+    another stream must not reuse it (the launch would run on the old stream, unordered with
+    the caller's work)."""
+    env = sw.VecSwimmerEnv(64, n=3)
+    act = torch.full((2, 64), 0.5, dtype=torch.float64, device="cuda:0")
+    env.reset()
+    env.step(act)
+    env.step(act)
+    assert len(env._plans) == 2
+    side = torch.cuda.Stream("cuda:0")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        env.step(act)
+        env.step(act)
+        side.synchronize()
+    assert len(env._plans) == 4
+    streams = {k[3] for k in env._plans}
+    assert streams == {torch.cuda.current_stream().cuda_stream, side.cuda_stream}
+    ref = sw.VecSwimmerEnv(64, n=3)
+    ref.reset()
+    for _ in range(4):
+        want, _, _, _ = ref.step(act)
+    assert torch.equal(env.get_state(), want)
+
+
+def _store_worker(rank, world, port, path, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import swimmer_amd as sw
+        out.put((rank, _store_run(sw, path)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _store_run(sw, path):
+    ep = sw.EnvParam("LeonSwimmer-Test", n=3, H=30, l_i=0.8, m_i=1.2, h=1e-3, k=10.2, epsilon=0)
+    ap = sw.ARSParam("Test", V1=True, n_iter=10, H=30, N=4, b=4, alpha=0.01, nu=0.02,
+                     safe=False, threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=6, device="cuda:0", record_trajectories=True)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        curve = agent.runTraining(save_data_path=path)
+    return curve
+
+
+def test_sharded_runs_store_every_rollout(sw, tmp_path):
+    """The reference appends EVERY rollout to its Database (ars_agent.py:172) and saves it every
+    10 iterations (:213-214).  With two ranks each rank stores its shard in its own file;
+    Database.load(path) reads them back, and together they are the single-process store."""
+    single = str(tmp_path / "single.npz")
+    curve1 = _store_run(sw, single)
+    world, shared = 2, str(tmp_path / "sharded.npz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_store_worker, args=(r, world, port, shared, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for _, curve in res:
+        assert np.array_equal(curve, curve1)
+    files = sorted(os.listdir(tmp_path))
+    assert "sharded.rank000of002.npz" in files and "sharded.rank001of002.npz" in files
+    assert "sharded.npz" not in files
+    a, b = sw.ars.database.Database(), sw.ars.database.Database()
+    a.load(single)
+    b.load(shared)
+    iters, per_it, per_rank = 11, 8, 4          # runTraining: 1 warm-up + 10 iterations
+    assert a.size == b.size == iters * per_it
+    ta, tb = np.array(a.trajectories), np.array(b.trajectories)
+    pa, pb = np.array(a.policies), np.array(b.policies)
+    for it in range(iters):
+        for r in range(per_it):
+            rank, local = divmod(r, per_rank)
+            j = rank * iters * per_rank + it * per_rank + local
+            assert np.array_equal(ta[it * per_it + r], tb[j])
+            assert np.array_equal(pa[it * per_it + r], pb[j])
