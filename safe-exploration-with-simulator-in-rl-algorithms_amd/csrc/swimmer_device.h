@@ -146,6 +146,132 @@ __device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_o
     c_out = __hiloint2double((int)((uint32_t)__double2hiint(cv) ^ cfl), __double2loint(cv));
 }
 
+// ---- angles kept in reduced form (segment-per-lane rollout kernels) -----------------------
+// theta = r + K (pi/2) with |r| <= pi/4: the rollout integrates r (r += h thetadot, the same
+// FMA the Euler update of theta is) and re-normalises -- rarely, on a wave-uniform branch -- when
+// |r| leaves [-pi/4, pi/4].  sin / cos then need NO per-step range reduction and NO quadrant
+// logic: the two minimax kernels on r and a rotation by the quarter turns (sa, sb) =
+// (cos, sin)(K pi/2), exact numbers in {0, +-1}: 4 instructions instead of 16.  The reduced angle
+// is the authoritative one; theta = fl(K pi/2 + r) is formed from it for the policy, the
+// trajectory and the statistics (one FMA, within an ulp of the angle the sin / cos are taken of).
+// Where the reference rounds theta to ulp(theta) every step, r is rounded to ulp(r) <= ulp(theta):
+// same equations, rounding differences of the order the reference's own step has.
+struct Angle {
+    double r;       // reduced angle
+    double kd;      // K, an exact integer
+    double sa, sb;  // cos(K pi/2), sin(K pi/2)
+};
+
+constexpr double kPio2Hi = 1.5707963267948966;      // fl(pi/2)
+constexpr double kPio2Lo = 6.123233995736766e-17;   // pi/2 - fl(pi/2)
+constexpr double kPio4 = 0.78539816339744830962;
+
+// Move whole quarter turns from r into (K, sa, sb); a no-op on lanes with |r| <= pi/4.  Valid for
+// |r| < kAngleLimit (callers flag larger start angles with SW_STATUS_RANGE).
+__device__ __forceinline__ void angle_renorm(Angle &A)
+{
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double km = __builtin_fma(A.r, 0.63661977236758134308, MAGIC);
+    const double k = km - MAGIC;
+    const uint32_t q = (uint32_t)__double_as_longlong(km);
+    double r = __builtin_fma(-k, kPio2Hi, A.r);      // exact
+    A.r = __builtin_fma(-k, kPio2Lo, r);
+    A.kd += k;
+    const double ck = (q & 1u) ? 0.0 : ((q & 2u) ? -1.0 : 1.0);
+    const double sk = (q & 1u) ? ((q & 2u) ? -1.0 : 1.0) : 0.0;
+    const double sa = A.sa * ck - A.sb * sk, sb = A.sa * sk + A.sb * ck;
+    A.sa = sa;
+    A.sb = sb;
+}
+
+// The per-step form of angle_renorm for the hot loops: ONE compare and ONE (normally not taken)
+// scalar branch; the re-normalisation behind it works IN PLACE on A and thmax.  Written as an asm
+// block because the compiler lays the same C++ out with the rare path as the fall-through and
+// five register copies on the common one.  No lane predication: lanes inside [-pi/4, pi/4] move
+// k = 0 quarter turns.  thmax <- max(thmax, |theta|) on that path: every way to a huge angle
+// leads through it (|theta| moves less than pi/2 between two re-normalisations).
+// magic = 1.5 * 2^52 in a VGPR pair (VOP3 takes one scalar operand on gfx9).
+__device__ __forceinline__ void angle_keep_reduced(Angle &A, double &thmax, double magic)
+{
+    double t0, t1, p, w;
+    int q, q1;
+    asm volatile(
+        "v_cmp_gt_f64_e64 vcc, |%[r]|, %[lim]\n\t"
+#ifdef SW_RENORM_INLINE
+        "s_cbranch_vccz .Lsw_reduced_%=\n\t"
+#else
+        // the rare path lives out of line (end of this function's section): the common path
+        // falls through an UNTAKEN branch
+        "s_cbranch_vccnz .Lsw_renorm_%=\n"
+        ".Lsw_reduced_%=:\n\t"
+        ".subsection 1\n"
+        ".Lsw_renorm_%=:\n\t"
+#endif
+        "v_fma_f64 %[t1], %[r], %[c2opi], %[magic]\n\t"     // k + magic
+        "v_add_f64 %[t0], %[t1], -%[magic]\n\t"             // k = rint(r * 2/pi)
+        "v_fma_f64 %[r], -%[t0], %[hi], %[r]\n\t"           // exact
+        "v_fma_f64 %[r], -%[t0], %[lo], %[r]\n\t"
+        "v_add_f64 %[kd], %[kd], %[t0]\n\t"
+        "v_cvt_i32_f64_e32 %[q], %[t0]\n\t"
+        "v_and_b32_e32 %[q1], 1, %[q]\n\t"
+        "v_and_b32_e32 %[q], 2, %[q]\n\t"
+        "v_cvt_f64_i32_e32 %[t0], %[q]\n\t"                 // 0 or 2
+        "v_add_f64 %[t0], 1.0, -%[t0]\n\t"                  // u = cos / sin of the even part
+        "v_cvt_f64_i32_e32 %[t1], %[q1]\n\t"                // odd: 0 or 1
+        "v_mul_f64 %[p], %[sa], %[t0]\n\t"
+        "v_mul_f64 %[w], %[sb], %[t0]\n\t"
+        "v_add_f64 %[t0], 1.0, -%[t1]\n\t"                  // even: 1 or 0
+        "v_mul_f64 %[sa], %[t0], %[p]\n\t"
+        "v_mul_f64 %[sb], %[t0], %[w]\n\t"
+        "v_fma_f64 %[sa], -%[t1], %[w], %[sa]\n\t"          // odd: (sa, sb) <- (-sb u, sa u)
+        "v_fma_f64 %[sb], %[t1], %[p], %[sb]\n\t"
+        "v_fma_f64 %[t0], %[kd], %[hi], %[r]\n\t"
+#ifdef SW_RENORM_INLINE
+        "v_max_f64 %[thmax], %[thmax], |%[t0]|\n"
+        ".Lsw_reduced_%=:"
+#else
+        "v_max_f64 %[thmax], %[thmax], |%[t0]|\n\t"
+        "s_branch .Lsw_reduced_%=\n\t"
+        ".subsection 0"
+#endif
+        : [r] "+v"(A.r), [kd] "+v"(A.kd), [sa] "+v"(A.sa), [sb] "+v"(A.sb), [thmax] "+v"(thmax),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [p] "=&v"(p), [w] "=&v"(w), [q] "=&v"(q), [q1] "=&v"(q1)
+        : [lim] "s"(kPio4), [c2opi] "s"(0.63661977236758134308), [hi] "s"(kPio2Hi),
+          [lo] "s"(kPio2Lo), [magic] "v"(magic)
+        : "vcc");
+}
+
+__device__ __forceinline__ Angle angle_make(double theta)
+{
+    Angle A{theta, 0.0, 1.0, 0.0};
+    angle_renorm(A);
+    return A;
+}
+
+__device__ __forceinline__ double angle_theta(const Angle &A)
+{
+    return __builtin_fma(A.kd, kPio2Hi, A.r);
+}
+
+__device__ __forceinline__ void sincos_angle(const Angle &A, double &s_out, double &c_out, const TrigK &K)
+{
+    const double r = A.r, z = r * r;
+    double ps = fma3_sc(K.s6, z, -2.50507602534068634195e-08);
+    ps = fma3_sc(ps, z, 2.75573137070700676789e-06);
+    ps = fma3_sc(ps, z, -1.98412698298579493134e-04);
+    ps = fma3_sc(ps, z, 8.33333333332248946124e-03);
+    ps = fma3_sc(ps, z, -1.66666666666666324348e-01);
+    double pc = fma3_sc(K.c6, z, 2.08757232129817482790e-09);
+    pc = fma3_sc(pc, z, -2.75573143513906633035e-07);
+    pc = fma3_sc(pc, z, 2.48015872894767294178e-05);
+    pc = fma3_sc(pc, z, -1.38888888888741095749e-03);
+    pc = fma3_sc(pc, z, 4.16666666666666019037e-02);
+    const double sr = __builtin_fma(r * z, ps, r);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    s_out = __builtin_fma(A.sa, sr, A.sb * cr);      // sin(r + K pi/2)
+    c_out = __builtin_fma(A.sa, cr, -(A.sb * sr));   // cos(r + K pi/2)
+}
+
 __device__ __forceinline__ void sincos_fast(double x, double &s_out, double &c_out)
 {
     sincos_fast(x, s_out, c_out, TrigK{1.58969099521155010221e-10, -1.13596475577881948265e-11});

@@ -37,6 +37,9 @@
 
 // cache policy of the trajectory stores of the segment-per-lane kernels (gfx940+ encoding:
 // 1 = sc0, 2 = nt, 16 = sc1); see DESIGN.md for the measurement behind the choice
+#ifndef SW_QUAD_UNROLL
+#define SW_QUAD_UNROLL 4
+#endif
 #ifndef SW_TRAJ_STORE_AUX
 #define SW_TRAJ_STORE_AUX 0
 #endif
@@ -692,10 +695,12 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
     // by the hardware range check, never written elsewhere).
     const uint32_t off_th = (uint32_t)(((int64_t)cth * n_roll + r) * 8);
     const uint32_t off_thd = (uint32_t)(((int64_t)cthd * n_roll + r) * 8);
-    // Gdot is replicated on every lane: segment 0's lanes record (store and sum) x, the others
-    // y.  ONE store of a per-lane selected value: a store costs ~16 issue cycles (measured), the
-    // select 2 x 4.4
-    const uint32_t off_g = (uint32_t)(((int64_t)(seg == 0 ? 0 : 1) * n_roll + r) * 8);
+    // Gdot is replicated on every lane (each lane integrates its own copy, equal up to rounding):
+    // lanes of segment 0 record (store and sum) x, the others y.  ONE store of a per-lane selected
+    // value: a store costs ~16 issue cycles (measured), the select 2 x 4.4.  The rollout's
+    // Gdot_y is lane 1's copy: lane 2's store is dropped by the buffer range check.
+    const uint32_t kDrop = 0xfffffff0u;
+    const uint32_t off_g = (q == 2) ? kDrop : (uint32_t)(((int64_t)(seg == 0 ? 0 : 1) * n_roll + r) * 8);
     const double selx = (seg == 0) ? 1.0 : 0.0, sely = 1.0 - selx;
     const uint32_t slab = (uint32_t)(D * n_roll * 8);
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
@@ -708,36 +713,52 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
     };
 
-    double thmax = 0.0, detmin = 1.0;
+    // The angle is carried in reduced form theta = r + K pi/2 (swimmer_device.h, Angle): no
+    // per-step range reduction or quadrant logic in sin / cos.
+    sw::Angle A = sw::angle_make(th);
+    double thmax = 0.0, det = 1.0;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
     double m1g = 0.0, m2g = 0.0;   // sums of this lane's Gdot component and its square
-    // neighbours' angle / angular velocity for the next step's policy: exchanged at the END of a
-    // step (behind the stores and moment updates), so the DPP reads never wait on the Euler
-    // update that just wrote them
-    double t1 = sw::dpp_f64<sw::kDppNext1>(th), t2 = sw::dpp_f64<sw::kDppNext2>(th);
+    // neighbours' angular velocities for the next step: exchanged at the END of a step (behind
+    // the stores and moment updates), so the DPP reads never wait on the Euler update that just
+    // wrote them.  The neighbours' ANGLES are never exchanged: the policy is linear in them and
+    // theta_j(t+1) = theta_j(t) + h thetadot_j(t), so the angle part of this lane's torque balance,
+    //     Th(t) = -V . mean + sum_j V[theta_j] theta_j(t),
+    // is carried along as Th(t+1) = Th(t) + sum_j (h V[theta_j]) thetadot_j(t) -- three FMAs on
+    // velocities that are exchanged anyway, instead of three FMAs on angles plus four DPP moves.
+    // (It also spares the per-step cancellation of V . theta against V . mean, ~1e4 against ~1
+    // once the whitening is on.)
     double w1 = sw::dpp_f64<sw::kDppNext1>(thd), w2 = sw::dpp_f64<sw::kDppNext2>(thd);
+    double Th = __builtin_fma(V[2], th, nbias);
+    Th = __builtin_fma(V[4], sw::dpp_f64<sw::kDppNext1>(th), Th);
+    Th = __builtin_fma(V[6], sw::dpp_f64<sw::kDppNext2>(th), Th);
+    const double hV2 = C.h * V[2], hV4 = C.h * V[4], hV6 = C.h * V[6];
     const sw::TrigK K = sw::trig_consts();
-    sw::Quad3Geo G = sw::quad3_geometry(th, K), Gn;
+    double magic = 6755399441055744.0;   // 1.5 * 2^52, pinned in a VGPR pair for angle_keep_reduced
+    asm volatile("" : "+v"(magic));
+    sw::Quad3Geo G = sw::quad3_geometry(A, K), Gn;
     // one step: consumes the geometry Gc of theta_t, produces Gx for theta_{t+1}
     auto one_step = [&](const sw::Quad3Geo &Gc, sw::Quad3Geo &Gx) {
-        asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
-        // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean); the
-        // neighbours' angles and angular velocities arrive by DPP (the velocities are reused
-        // by the physics step)
-        double tqa = __builtin_fma(V[0], gdx, nbias), tqb = V[1] * gdy;
-        tqa = __builtin_fma(V[2], th, tqa);
-        tqb = __builtin_fma(V[3], thd, tqb);
-        tqa = __builtin_fma(V[4], t1, tqa);
-        tqb = __builtin_fma(V[5], w1, tqb);
-        tqa = __builtin_fma(V[6], t2, tqa);
-        tqb = __builtin_fma(V[7], w2, tqb);
+        // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean): the carried
+        // angle part + the velocity part (the neighbours' angular velocities arrive by DPP and are
+        // reused by the physics step).  One accumulator: the kernel is issue-bound, not chain-bound.
+        double tq = __builtin_fma(V[0], gdx, Th);
+        tq = __builtin_fma(V[1], gdy, tq);
+        tq = __builtin_fma(V[3], thd, tq);
+        tq = __builtin_fma(V[5], w1, tq);
+        tq = __builtin_fma(V[7], w2, tq);
+        Th = __builtin_fma(hV2, thd, Th);
+        Th = __builtin_fma(hV4, w1, Th);
+        Th = __builtin_fma(hV6, w2, Th);
         // theta_{t+1} needs thetadot_t only: its sin / cos and the neighbour exchange run
         // beside this step's solve (software pipelining across steps, swimmer_quad3.h)
-        const double th_next = __builtin_fma(C.h, thd, th);
-        Gx = sw::quad3_geometry(th_next, K);
-        const double det = sw::quad3_dynamics(C, L, Gc, gdx, gdy, thd, w1, w2, tqa + tqb);
+        A.r = __builtin_fma(C.h, thd, A.r);
+        sw::angle_keep_reduced(A, thmax, magic);   // compare + untaken branch; rare re-normalisation
+        const double th_next = sw::angle_theta(A);
+        Gx = sw::quad3_geometry(A, K);
+        det = sw::quad3_dynamics(C, L, Gc, gdx, gdy, thd, w1, w2, tq);
         th = th_next;
-        asm("v_min_f64 %0, %1, %2" : "=v"(detmin) : "v"(detmin), "v"(det));
         // the return comes out of the per-component sums in the epilogue (linearity), no
         // per-step reward arithmetic
         const double gsel = __builtin_fma(selx, gdx, sely * gdy);
@@ -756,18 +777,29 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
             m2thd = __builtin_fma(thd, thd, m2thd);
             m2g = __builtin_fma(gsel, gsel, m2g);
         }
-        t1 = sw::dpp_f64<sw::kDppNext1>(th);
-        t2 = sw::dpp_f64<sw::kDppNext2>(th);
         w1 = sw::dpp_f64<sw::kDppNext1>(thd);
         w2 = sw::dpp_f64<sw::kDppNext2>(thd);
     };
-    // two steps per trip, the geometry ping-pongs between G and Gn (no register copies)
+    // four steps per trip, the geometry ping-pongs between G and Gn (no register copies)
     int32_t t = 0;
+#if SW_QUAD_UNROLL == 4
+    for (; t + 4 <= H; t += 4) {
+        one_step(G, Gn);
+        one_step(Gn, G);
+        one_step(G, Gn);
+        one_step(Gn, G);
+    }
+#endif
     for (; t + 2 <= H; t += 2) {
         one_step(G, Gn);
         one_step(Gn, G);
     }
     if (t < H) one_step(G, Gn);
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
+    // the joint-acceleration system is the chain's (scaled) mass matrix: positive definite for
+    // every finite configuration, so its determinant can only fail to be positive once the state
+    // is no longer finite -- the last step's says so
+    const double detmin = det;
 
     // ---- per-rollout outputs (quad lanes 0..2 hold the state; lane 0 the return) ----
     int code = ((detmin > 0.0) ? 0 : SW_STATUS_SINGULAR) |
@@ -885,14 +917,17 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     };
 
     double thmax = 0.0, pivmin_all = 1.0;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
     double sgx = 0.0, sgy = 0.0, qgx = 0.0, qgy = 0.0;   // sums of Gdot and Gdot^2 over the steps
     const sw::TrigK K = sw::trig_consts();
+    double magic = 6755399441055744.0;   // 1.5 * 2^52, pinned in a VGPR pair for angle_keep_reduced
+    asm volatile("" : "+v"(magic));
+    sw::Angle A = sw::angle_make(th);    // theta = r + K pi/2 (swimmer_device.h)
     for (int32_t t = 0; t < H; ++t) {
-        asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
         // policy + physics of one step (swimmer_row.h); the other segments' angles and angular
         // velocities are read straight out of their lanes by fused broadcast-FMAs
-        const double rq = sw::row_step<N>(C, L, V, nbias, K, gdx, gdy, th, thd);
+        const double rq = sw::row_step<N>(C, L, V, nbias, K, magic, gdx, gdy, A, th, thd, thmax);
         asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
         // the return comes out of the per-component sums in the epilogue (linearity)
         sgx += gdx;
@@ -915,6 +950,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         }
     }
 
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
     // ---- per-rollout outputs ----
     {
         double bad[N], big[N], piv[N];

@@ -21,8 +21,9 @@
 //   (own, next1, next2) and keeps only its own component (closed-form cofactor row, one
 //   reciprocal), so no lane-dependent code is needed: all lane dependence sits in a few
 //   per-lane constants (chain weights for its rotation) loaded in the prologue.
-//   Gdot is replicated per lane and re-synchronised from lane 0 after every step, so the
-//   state of a rollout is well defined: Gdot from lane 0, (theta_i, thetadot_i) from lane i.
+//   Gdot is replicated per lane (each lane integrates its own copy, equal up to rounding);
+//   the state of a rollout is: Gdot_x from lane 0, Gdot_y from lane 1, (theta_i, thetadot_i)
+//   from lane i.
 //
 //   The angle-only part of step t+1 (sin/cos, their exchange, pairwise cos/sin of differences)
 //   is evaluated beside step t's solve: theta_{t+1} needs thetadot_t only (Quad3Geo).
@@ -95,10 +96,10 @@ struct Quad3Geo {
     double ss1, ss2;               // sin(th_i1 - th_i), sin(th_i2 - th_i)
 };
 
-__device__ __forceinline__ Quad3Geo quad3_geometry(double th, const TrigK &K)
+__device__ __forceinline__ Quad3Geo quad3_geometry(const Angle &A, const TrigK &K)
 {
     Quad3Geo G;
-    sincos_fast(th, G.s, G.c, K);
+    sincos_angle(A, G.s, G.c, K);
     G.s1 = dpp_f64<kDppNext1>(G.s);
     G.c1 = dpp_f64<kDppNext1>(G.c);
     G.s2 = dpp_f64<kDppNext2>(G.s);
@@ -130,15 +131,14 @@ __device__ __forceinline__ double quad3_dynamics(const Consts &C, const Quad3Lan
     // barycentre acceleration (rotated summation order; re-synchronised below)
     const double sx = __builtin_fma(g2, G.s2, __builtin_fma(g1, G.s1, g * G.s));
     const double sy = __builtin_fma(g2, G.c2, __builtin_fma(g1, G.c1, g * G.c));
-    // this segment's row of Q thdd = r
-    double cent = (L.t1 * (w1 * w1)) * G.ss1;
+    // this segment's row of Q thdd = r (the accumulation starts from the torque balance)
+    double cent = __builtin_fma(L.t1 * (w1 * w1), G.ss1, tq_scaled);
     cent = __builtin_fma(L.t2 * (w2 * w2), G.ss2, cent);
     double fric = L.a0 * g;
     fric = __builtin_fma(L.a1 * G.cc1, g1, fric);
     fric = __builtin_fma(L.a2 * G.cc2, g2, fric);
     double r0 = __builtin_fma(-C.six_k_m, fric, cent);
     r0 = __builtin_fma(C.kl_m, thd, r0);
-    r0 += tq_scaled;
     const double r1 = dpp_f64<kDppNext1>(r0), r2 = dpp_f64<kDppNext2>(r0);
     // first row of the adjugate of [[d0,a,b],[a,d1,e],[b,e,d2]]
     const double a = L.t1 * G.cc1, b = L.t2 * G.cc2, e = L.t12 * G.cc12;
@@ -153,9 +153,10 @@ __device__ __forceinline__ double quad3_dynamics(const Consts &C, const Quad3Lan
     gdx = __builtin_fma(C.h_kl_nm, sx, gdx);
     gdy = __builtin_fma(-C.h_kl_nm, sy, gdy);
     thd = __builtin_fma(C.h, tdd, thd);
-    // one authoritative Gdot per rollout: lane 0's
-    gdx = dpp_f64<kDppLane0>(gdx);
-    gdy = dpp_f64<kDppLane0>(gdy);
+    // Gdot is NOT re-synchronised across the quad: the lanes sum the same three terms in their
+    // own rotated order, so their copies differ by rounding (~1e-17 per step) and each lane
+    // integrates its own -- three roundings of one contracting ODE (friction), which stay
+    // within ~1e-16 of each other.  The rollout's Gdot_x is lane 0's copy, Gdot_y lane 1's.
     return det;
 }
 

@@ -116,14 +116,17 @@ struct RowEliminate {
 // One explicit-Euler step.  gdx, gdy: replicated (bit-identical on all lanes); th, thd: own
 // segment; V: this lane's pre-combined policy row, nbias = -V . mean.  Returns this lane's
 // reciprocal pivot (positive for a positive definite system).
+// The angle is carried in reduced form (Angle, swimmer_device.h): A is authoritative, th =
+// fl(K pi/2 + r) is what the policy, the trajectory and the statistics see; thmax collects
+// |theta| whenever an angle is re-normalised (SW_STATUS_RANGE).
 template <int N>
 __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
                                            const double (&V)[2 * N + 2], double nbias,
-                                           const TrigK &K, double &gdx, double &gdy, double &th,
-                                           double &thd)
+                                           const TrigK &K, double magic, double &gdx, double &gdy,
+                                           Angle &A, double &th, double &thd, double &thmax)
 {
     double s, c;
-    sincos_fast(th, s, c, K);
+    sincos_angle(A, s, c, K);
     double sk[N], ck[N];
     RowGather<N>::run(s, sk);
     RowGather<N>::run(c, ck);
@@ -149,7 +152,9 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
     RowFused<N>::velocity(g, r, thd, sq, vc, tc);
     double sx = 0.0, sy = 0.0;
     RowFused<N>::sums(sx, sy, r, g, sk, ck, ac);
-    th = __builtin_fma(C.h, thd, th);                 // explicit Euler: the OLD thetadot
+    A.r = __builtin_fma(C.h, thd, A.r);               // explicit Euler: the OLD thetadot
+    angle_keep_reduced(A, thmax, magic);              // compare + untaken branch
+    th = angle_theta(A);
     // everything the elimination reads by DPP is written before the first pivot is broadcast
     RowFused<N>::fence(a);
     RowEliminate<N>::run(L, a, r);
