@@ -41,14 +41,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MEASURED_COPY_PEAK_GBPS = 5690.0   # scripts/ubench/stream_copy on the box (profiles/r01_g_stream_copy.log)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-# Instructions one wave issues per env-step in the segment-per-lane rollout kernels (ISA count
-# of the hot loop incl. trajectory stores + moments, scripts/isa_loop_stats.py) and the measured
-# issue interval of a lone wave (profiles/r01_ubench_issue_cost.log: 1.92-2.13 ns per
-# independent instruction of any kind): what actually bounds the latency-bound rollout.
-ROLLOUT_INSTR_PER_STEP = {3: 145, 6: 256}
+# Instructions one wave issues per env-step in the segment-per-lane rollout kernels: ISA count of
+# the hot loop incl. trajectory stores + moments (scripts/isa_loop_stats.py, the out-of-line
+# re-normalisation blocks not counted): (f64 VALU, everything else).  Round 1: 145 / 256 in all.
+ROLLOUT_INSTR_PER_STEP = {3: (98, 26), 6: (214, 31)}
+# Measured issue interval of a lone wave (profiles/r01_ubench_issue_cost.log): an independent f64
+# FMA / multiply 2.12 ns, a 32-bit move / DPP move / SALU 1.92-2.03 ns: what actually bounds the
+# latency-bound rollout (boxes differ by ~2 % in clock, so the fraction can come out just above 1).
+LONE_WAVE_NS_F64 = 2.12
+LONE_WAVE_NS_OTHER = 1.98
 TIME_EVERY = 4                  # HIP events around every 4th rollout launch of the timed region
 POSTPASS_LAUNCHES = 16          # + every launch of an untimed post-pass
-LONE_WAVE_NS_PER_INSTR = 1.90   # lower edge of the measured per-instruction intervals (v_mov_b64 1.92, f64 + SALU 1.98, f64 FMA 2.13; DPP-heavy mixes come in slightly under)
 
 
 def parse(argv=None):
@@ -155,14 +158,16 @@ def pmc_traffic(kernel, n, directions, H):
 
 
 def issue_bound(n, H, kern_ms):
-    """The rollout kernel's real ceiling: every wave runs alone on its SIMD and can issue one
-    instruction per ~2.1 ns, so a rollout batch cannot finish faster than
-    H x instructions-per-step x that interval, whatever the batch size."""
+    """The rollout kernel's real ceiling: every wave runs alone on its SIMD and issues one
+    instruction per ~2 ns, so a rollout batch cannot finish faster than
+    H x (instructions per step x their issue intervals), whatever the batch size."""
     if n not in ROLLOUT_INSTR_PER_STEP or not kern_ms:
         return None
-    floor_ms = H * ROLLOUT_INSTR_PER_STEP[n] * LONE_WAVE_NS_PER_INSTR * 1e-6
-    return {"instructions_per_step": ROLLOUT_INSTR_PER_STEP[n],
-            "lone_wave_ns_per_instruction": LONE_WAVE_NS_PER_INSTR,
+    f64, other = ROLLOUT_INSTR_PER_STEP[n]
+    floor_ms = H * (f64 * LONE_WAVE_NS_F64 + other * LONE_WAVE_NS_OTHER) * 1e-6
+    return {"instructions_per_step": f64 + other, "f64_instructions_per_step": f64,
+            "lone_wave_ns_per_f64_instruction": LONE_WAVE_NS_F64,
+            "lone_wave_ns_per_other_instruction": LONE_WAVE_NS_OTHER,
             "floor_ms": floor_ms, "frac": floor_ms / kern_ms}
 
 
