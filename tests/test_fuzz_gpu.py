@@ -34,3 +34,65 @@ def test_violent_policies_stay_close_to_the_oracle(n, scale):
     print(f"n={n} scale={scale}: |state| up to {np.abs(ref_traj).max():.1f}, "
           f"relative deviation lane {worst['lane']:.2e} quad/row {worst['quad']:.2e}")
     assert max(worst.values()) <= 1e-8
+
+
+@pytest.mark.parametrize("n", [3, 5, 6])
+def test_angles_carried_in_reduced_form_across_many_quadrants(n):
+    """The segment-per-lane kernels carry theta = r + K pi/2 and re-normalise r on a rare path
+    written in assembly (swimmer_device.h, angle_keep_reduced).  Start states spread over +-50 rad
+    (negative angles, every quadrant) with angular velocities up to +-30 rad/s (0.03 rad per step:
+    every segment crosses several re-normalisation boundaries, in both directions, in 120 steps)
+    against the oracle, which evaluates libm sin / cos of the full angle every step."""
+    import swimmer_amd as sw
+    rng = np.random.default_rng(7 + n)
+    d, m, R, H = 2 * n + 2, n - 1, 64, 120
+    l, mm, k, h = PARAM_SETS["default"]
+    st = np.empty((R, d))
+    st[:, 0:2] = rng.uniform(-0.5, 0.5, (R, 2))
+    st[:, 2::2] = rng.uniform(-50.0, 50.0, (R, n))
+    st[:, 3::2] = rng.uniform(-30.0, 30.0, (R, n))
+    st[:8, 2::2] = np.round(st[:8, 2::2] / (np.pi / 4)) * (np.pi / 4)     # on the re-normalisation boundaries
+    pol = 0.05 * rng.uniform(-1, 1, (R, m, d))
+    op = oracle.OracleParams.make(n, l, mm, k, h)
+    ref = [oracle.rollout(op, H, pol[r], state0=st[r]) for r in range(R)]
+    ref_ret = np.array([x[0] for x in ref])
+    ref_traj = np.array([x[1] for x in ref])
+    s0 = torch.as_tensor(np.ascontiguousarray(st.T), device="cuda:0")
+    for kernel in ("lane", "quad"):
+        p = sw.SwParams.make(n, l, mm, k, h, flags=sw._lib.kernel_flags(kernel))
+        traj = torch.empty((H, d, R), dtype=torch.float64, device="cuda:0")
+        fin = torch.empty((d, R), dtype=torch.float64, device="cuda:0")
+        status = torch.zeros(R, dtype=torch.int32, device="cuda:0")
+        ret = sw.kernels.rollout(p, H, torch.as_tensor(pol, device="cuda:0"), state0=s0, traj=traj,
+                                 final_state=fin, status=status)
+        tr = traj.permute(2, 0, 1).cpu().numpy()
+        assert int(status.abs().sum()) == 0
+        dev = np.abs(tr - ref_traj).max() / np.abs(ref_traj).max()
+        print(f"n={n} {kernel}: |theta| up to {np.abs(ref_traj[:, :, 2::2]).max():.0f} rad, "
+              f"relative deviation {dev:.2e}")
+        assert dev <= 1e-9
+        assert np.abs(ret.cpu().numpy() - ref_ret).max() <= 1e-8 * max(1.0, np.abs(ref_ret).max())
+        assert np.array_equal(fin.T.cpu().numpy(), tr[:, -1, :])
+
+
+@pytest.mark.parametrize("kernel", ["lane", "quad"])
+@pytest.mark.parametrize("n", [3, 6])
+def test_rollout_status_bits_for_hopeless_inputs(n, kernel):
+    """Start angle beyond the supported range -> SW_STATUS_RANGE and a NaN return; a policy that
+    blows the swimmer up -> flagged (range or non-finite), never silent garbage, never a hang."""
+    import swimmer_amd as sw
+    d, m, R, H = 2 * n + 2, n - 1, 20, 300
+    p = sw.SwParams.make(n, flags=sw._lib.kernel_flags(kernel))
+    st = sw.kernels.reset(p, R)
+    st[2, 3] = 5.0e9                                   # rollout 3 starts out of range
+    pol = torch.zeros((R, m, d), dtype=torch.float64, device="cuda:0")
+    pol[7] = 1.0e7                                     # rollout 7: positive feedback on everything
+    status = torch.zeros(R, dtype=torch.int32, device="cuda:0")
+    ret = sw.kernels.rollout(p, H, pol, state0=st, status=status)
+    torch.cuda.synchronize()
+    s = status.cpu().numpy()
+    assert s[3] & 4 and bool(torch.isnan(ret[3]))
+    assert s[7] & (2 | 4), s[7]
+    ok = np.ones(R, dtype=bool)
+    ok[[3, 7]] = False
+    assert (s[ok] == 0).all() and bool(torch.isfinite(ret[torch.as_tensor(ok)]).all())
