@@ -5,16 +5,19 @@
 // 1024 SIMDs x 64 lanes.  With one rollout per lane (rollout_kernel) a batch of 1024
 // rollouts occupies 16 SIMDs and its speed is the length of one lane's instruction stream
 // (~310 instructions per step, one instruction per ~4.4 cycles for a lone wave,
-// scripts/ubench).  Spreading a rollout over the lanes of a quad cuts that stream to 145
-// instructions per step at 4x the (idle anyway) SIMD count:
+// scripts/ubench).  Spreading a rollout over the lanes of a quad cuts that stream to 124
+// instructions per step (round 1: 145) at 4x the (idle anyway) SIMD count:
 //
 //   lane q = 0,1,2 of a quad owns segment q: its angle, angular velocity, sin/cos, its row
 //   of the 3x3 joint-acceleration system and its V2 moment sums.  The joint torques are never
 //   formed: lane i only needs u_{i-1} - u_i, which is linear in the observation, so it holds
 //   the pre-combined policy row V_i = 12/(m l^2) (W_{i-1} - W_i) (columns in its rotated
-//   order) and evaluates one 8-term dot product on the observation (the mean enters as one
-//   constant per rollout); lane 3 mirrors lane 0 bit for bit (same inputs, same permutation
-//   sources), so whatever it stores duplicates lane 0's stores.
+//   order) and evaluates one dot product on the observation (the mean enters as one constant
+//   per rollout; the angle part is carried from step to step instead of re-evaluated, so the
+//   neighbours' angles are never exchanged); lane 3 mirrors lane 0 bit for bit (same inputs,
+//   same permutation sources), so whatever it stores duplicates lane 0's stores.
+//   Angles are carried in reduced form theta = r + K pi/2 (swimmer_device.h, Angle): sin / cos
+//   need no per-step range reduction and no quadrant logic.
 //   Neighbour data moves with DPP quad_perm moves (no LDS, no memory, two 32-bit moves per
 //   double): next1 = segment (q+1)%3, next2 = segment (q+2)%3.
 //   Every lane solves the SAME symmetric 3x3 system in its own rotated order
@@ -40,7 +43,6 @@ namespace sw {
 // quad_perm control words: lane j of a quad reads lane perm[j]
 constexpr int kDppNext1 = 1 | (2 << 2) | (0 << 4) | (1 << 6);  // [1,2,0,1]
 constexpr int kDppNext2 = 2 | (0 << 2) | (1 << 4) | (2 << 6);  // [2,0,1,2]
-constexpr int kDppLane0 = 0;                                   // [0,0,0,0]
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
