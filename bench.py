@@ -500,6 +500,9 @@ def run_rank(args):
             aux["shard_n3_256_directions"] = aux_ars_shard(sw, torch, 3, H, 256, device)
             aux["shard_n6_256_directions"] = aux_ars_shard(sw, torch, 6, H, 256, device)
             aux["rollout_saturated"] = aux_rollout_saturated(sw, torch, device)
+            # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
+            # than with four (16.8 GB, a 2 MB stride between the rows a step writes)
+            aux["rollout_saturated_65536"] = aux_rollout_saturated(sw, torch, device, n_roll=65536)
         if aux:
             line["aux"] = aux
         if not args.no_cpu_baseline and world == 1:

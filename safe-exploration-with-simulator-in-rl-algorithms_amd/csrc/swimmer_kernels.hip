@@ -35,13 +35,19 @@
 #include "swimmer_row.h"
 #include "swimmer_twin.h"
 
-// cache policy of the trajectory stores of the segment-per-lane kernels (gfx940+ encoding:
-// 1 = sc0, 2 = nt, 16 = sc1); see DESIGN.md for the measurement behind the choice
+// steps per trip of the quad kernel's loop (measurement knob; 2 measured +5 ns per step)
 #ifndef SW_QUAD_UNROLL
 #define SW_QUAD_UNROLL 4
 #endif
+// Cache policy of the trajectory stores of the segment-per-lane kernels (gfx940+ encoding:
+// 1 = sc0, 2 = nt, 16 = sc1).  sc1 = device-scope write-through: the 65 MB a launch stores do not
+// pile up as dirty lines in the XCDs' L2s, so the write-back at the end of the kernel -- which sits
+// on the critical path rollout -> update -- is short.  Same-box A/B (profiles/r02_d_ab_store_policy.log):
+// plain 0.2564 ms per launch / 0.2675 ms per iteration, nt 0.2550 / 0.2658, sc0 0.2566 / 0.2673,
+// sc1 0.2520 / 0.2628 (sc0 + sc1 and sc1 + nt the same as sc1).  (The lane kernel's stores in the
+// saturated regime gain nothing from nontemporal stores: 4.58 vs 4.55 TB/s, scripts/saturated_probe.py.)
 #ifndef SW_TRAJ_STORE_AUX
-#define SW_TRAJ_STORE_AUX 0
+#define SW_TRAJ_STORE_AUX 16
 #endif
 
 namespace {
@@ -1182,31 +1188,44 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         // come from its sums about the pivot c (reset state; every rollout starts there, so
         // |mean_b - c| is never large against the batch's spread), and the merge itself adds
         // non-negative terms only -- no cancellation that grows with the length of training.
-        // Thread (rg, j) = (tid / 64, tid % 64) sums column j over the rows whose GLOBAL index
-        // (rank-major) is congruent to rg mod 4, in ascending order with eight loads in flight;
-        // the four partial sums are combined in a fixed tree.  Global row indices make the
-        // grouping -- and every bit of the result -- independent of the world size for
-        // row-aligned shards, and identical on every rank.
-        __shared__ double part[kUpdBlock / kWave][kWave];
-        __shared__ double bsum[kWave];
-        const int j = threadIdx.x & 63, rg = threadIdx.x >> 6;
+        // The workgroup's 256 threads form G = 256 / 2d row groups x 2d columns: thread (rg, j) sums
+        // column j over the rows whose GLOBAL index (rank-major) is congruent to rg mod G, in
+        // ascending order, eight loads in flight per round (one round up to 8 G rows: 128 rows for
+        // n = 3) -- the loop used to run over 4 row groups only and paid one memory latency per 16
+        // rows, 4 rounds at 512 directions.  The G partial sums are added in ascending group
+        // order.  Global row indices make the grouping -- and every bit of the result --
+        // independent of the world size for row-aligned shards, and identical on every rank.
+        constexpr int kMaxCols = 2 * (2 * SW_MAX_SEGMENTS + 2);     // 2d <= 36
+        constexpr int kMaxGroups = kUpdBlock / 12;                  // 2d >= 12 (n = 2): G <= 21 (16 for n = 3)
+        __shared__ double part[kMaxGroups][kMaxCols];
+        __shared__ double bsum[kMaxCols];
+        const int cols = 2 * d, G = kUpdBlock / cols;
+        const int rg = threadIdx.x / cols, j = threadIdx.x - rg * cols;
         const int32_t total = gv.world * gv.rows_chunk;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        if (j < 2 * d) {
-            for (int32_t g0 = rg; g0 < total; g0 += 16) {
+        if (rg < G) {
+            double acc = 0.0;
+            for (int32_t g0 = rg; g0 < total; g0 += 8 * G) {
+                double v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int32_t g = g0 + 4 * q;
+                for (int q = 0; q < 8; ++q) {
+                    const int32_t g = g0 + q * G;
+                    v[q] = 0.0;
                     if (g < total) {
                         const int32_t r = g / gv.rows_chunk, row = g - r * gv.rows_chunk;
-                        acc[q] += gv.mom_base[r * gv.seg_len + (int64_t)row * (2 * d) + j];
+                        v[q] = gv.mom_base[r * gv.seg_len + (int64_t)row * cols + j];
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q];
             }
+            part[rg][j] = acc;
         }
-        part[rg][j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
-        if (rg == 0) bsum[j] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+        if (threadIdx.x < cols) {
+            double t = part[0][threadIdx.x];
+            for (int g = 1; g < G; ++g) t += part[g][threadIdx.x];
+            bsum[threadIdx.x] = t;
+        }
         __syncthreads();
         const double n0 = running[0], n1 = n0 + n_new;
         if (threadIdx.x < d && n_new > 0.0) {
