@@ -497,6 +497,8 @@ def run_rank(args):
             aux["step_only"] = aux_step_only(sw, torch, n, device)
             s2048 = aux_ars_shard(sw, torch, n, H, 2048, device)
             aux["ars_2048_directions_one_gpu"] = s2048     # configs[3]'s whole problem on ONE GPU
+            if n != 6:   # configs[4]'s whole problem on ONE GPU (4096 rollouts = a wave on every SIMD)
+                aux["ars_2048_directions_one_gpu_n6"] = aux_ars_shard(sw, torch, 6, H, 2048, device)
             aux["shard_n3_256_directions"] = aux_ars_shard(sw, torch, 3, H, 256, device)
             aux["shard_n6_256_directions"] = aux_ars_shard(sw, torch, 6, H, 256, device)
             aux["rollout_saturated"] = aux_rollout_saturated(sw, torch, device)
