@@ -96,3 +96,41 @@ def test_rollout_status_bits_for_hopeless_inputs(n, kernel):
     ok = np.ones(R, dtype=bool)
     ok[[3, 7]] = False
     assert (s[ok] == 0).all() and bool(torch.isfinite(ret[torch.as_tensor(ok)]).all())
+
+
+@pytest.mark.parametrize("kernel", ["lane", "quad"])
+@pytest.mark.parametrize("n", [3, 6])
+def test_mirror_symmetry_of_whole_rollouts_at_baseline_size(n, kernel):
+    """A size-independent property at BASELINE size (1024 rollouts x H = 1000), no oracle needed:
+    reflecting the swimmer about the x axis, M = diag(1, -1, -1, -1, ...) on (Gdx, Gdy, th_i,
+    thd_i), flips the sign of every joint torque, so the V1 policy P' = -P M started from the
+    mirrored state runs the mirrored trajectory and collects the SAME return (reward = Gdot_x).
+    Exercises negative angles (start at -pi/2), the reduced-angle tracking in both directions and
+    every sign in the dynamics."""
+    import swimmer_amd as sw
+    rng = np.random.default_rng(31 + n)
+    d, m, R, H = 2 * n + 2, n - 1, 1024, 1000
+    p = sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3, flags=sw._lib.kernel_flags(kernel))
+    M = -np.ones(d)
+    M[0] = 1.0
+    pol = 0.3 * rng.uniform(-1, 1, (R, m, d))
+    st = np.zeros((d, R))
+    st[2::2] = np.pi / 2 + rng.uniform(-0.3, 0.3, (n, R))
+    st[3::2] = rng.uniform(-1, 1, (n, R))
+    st[0:2] = rng.uniform(-0.2, 0.2, (2, R))
+    dev = "cuda:0"
+    out = []
+    for sign, s0, pl in ((1, st, pol), (-1, M[:, None] * st, -pol * M[None, None, :])):
+        traj = torch.empty((H, d, R), dtype=torch.float64, device=dev)
+        status = torch.zeros(R, dtype=torch.int32, device=dev)
+        ret = sw.kernels.rollout(p, H, torch.as_tensor(np.ascontiguousarray(pl), device=dev),
+                                 state0=torch.as_tensor(np.ascontiguousarray(s0), device=dev), traj=traj,
+                                 status=status)
+        assert int(status.abs().sum()) == 0
+        out.append((ret.cpu().numpy(), traj.cpu().numpy()))
+    (r1, t1), (r2, t2) = out
+    scale = np.abs(t1).max()
+    dev_t = np.abs(t1 - M[None, :, None] * t2).max() / scale
+    dev_r = np.abs(r1 - r2).max() / max(1.0, np.abs(r1).max())
+    print(f"n={n} {kernel}: mirrored rollouts deviate by {dev_t:.2e} (states), {dev_r:.2e} (returns)")
+    assert dev_t <= 1e-9 and dev_r <= 1e-9
