@@ -142,6 +142,23 @@ def launch_ranks(world, argv, script=None, timeout=None):
     return rc
 
 
+class stdout_to_stderr(object):
+    """File-descriptor-level redirect of stdout to stderr: RCCL prints a version banner to fd 1
+    when its first communicator comes up, and stdout is reserved for the ONE result line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 # ---------------------------------------------------------------------------------------
 def pmc_traffic(kernel, n, directions, H):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None when
@@ -333,6 +350,38 @@ def leg_roofline(n, n_local, H, kern_ms):
             "issue_bound": issue_bound(n, H, kern_ms)}
 
 
+def aux_collective_one_rank(sw, torch, n, H, directions, device, iters=20):
+    """What the per-iteration all-gather costs BEFORE any wire time: the same ARS loop with a
+    one-rank RCCL process group and the collective forced (ProcessGroupNCCL + the RCCL kernel on
+    the critical stream).  The multi-GPU iteration is this plus the time on the xGMI links."""
+    import numpy as np
+    import torch.distributed as dist
+    from swimmer_amd.ars import sharding
+    state = np.random.get_state()
+    try:
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0,
+                                    world_size=1, device_id=torch.device(device))
+            dist.barrier()      # the communicator (and its banner) come up here at the latest
+    except Exception as exc:   # noqa: BLE001 -- reported in the line, never fatal for the N = 1 bench
+        return {"error": f"one-rank RCCL group: {exc}"}
+    try:
+        sharding._FORCE_COLLECTIVE = True
+        leg = ArsLeg(sw, torch, n, H, directions, device)
+        with stdout_to_stderr():
+            r = leg.run(3, iters, torch.cuda.synchronize, time_every=4, postpass=16)
+        leg.check(0)
+        return {"directions": directions, "ms_per_iteration": r["seconds"] / iters * 1e3,
+                "collective_us": r.get("collective_us"), "backend": dist.get_backend(),
+                "note": "one rank, all-gather forced: framework + RCCL launch cost per iteration, no wire time"}
+    except Exception as exc:   # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        sharding._FORCE_COLLECTIVE = False
+        np.random.set_state(state)
+        dist.destroy_process_group()
+
+
 def aux_ars_shard(sw, torch, n, H, directions, device, iters=12):
     """One GPU's shard of a sharded config (configs[3]: n = 3, configs[4]: n = 6; 2048
     directions over 8 GPUs = 256 per GPU) as a self-contained ARS iteration loop."""
@@ -371,10 +420,12 @@ def run_rank(args):
     device = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(device))
-        else:
-            dist.init_process_group(backend)
+        with stdout_to_stderr():    # RCCL / gloo banners must not land in front of the result line
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(device))
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
 
     import swimmer_amd as sw
     sw._lib.load()
@@ -501,6 +552,7 @@ def run_rank(args):
                 aux["ars_2048_directions_one_gpu_n6"] = aux_ars_shard(sw, torch, 6, H, 2048, device)
             aux["shard_n3_256_directions"] = aux_ars_shard(sw, torch, 3, H, 256, device)
             aux["shard_n6_256_directions"] = aux_ars_shard(sw, torch, 6, H, 256, device)
+            aux["collective_one_rank"] = aux_collective_one_rank(sw, torch, n, H, args.directions, device)
             aux["rollout_saturated"] = aux_rollout_saturated(sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)

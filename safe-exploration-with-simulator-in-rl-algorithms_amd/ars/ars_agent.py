@@ -36,6 +36,7 @@ from .._lib import (SwParams, SwimmerHipError, kernel_flags, numpy_global_unifor
                     require_gpu)
 from .database import Database
 from .environment import Environment
+from . import sharding as _sh
 from .sharding import (all_gather_segments, returns_from_segments, segment_len,
                        shard_bounds)
 
@@ -121,7 +122,6 @@ class ARSAgent(object):
         width = 2 * self.d
         self._seg_len = segment_len(self.chunk, self.rows_chunk, width)
         self._send = torch.zeros(self._seg_len, **f64)
-        from . import sharding as _sh
         self._gathered = (torch.zeros(self.world * self._seg_len, **f64)
                           if (self.world > 1 or _sh._FORCE_COLLECTIVE) else self._send)
         self._returns_local = self._send[:2 * self.n_local]
@@ -257,7 +257,7 @@ class ARSAgent(object):
                             self._mean, self._inv_std, self._returns_local, self._traj,
                             self._moments_local,
                             self._cov_acc if self._traj is not None else None, self._status)
-        if self._coll_events is not None and self.world > 1:
+        if self._coll_events is not None and (self.world > 1 or _sh._FORCE_COLLECTIVE):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
