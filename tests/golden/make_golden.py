@@ -270,6 +270,69 @@ def gen_ars():
     print("ars.npz", len(out))
 
 
+def _ars_case(out, tag, n, pset, V1, N, b, H, alpha, nu, seed, iters):
+    l_i, m_i, k, h = PARAM_SETS[pset]
+    ep = EnvParam("LeonSwimmer-Golden", n=n, H=H, l_i=l_i, m_i=m_i, h=h, k=k, epsilon=0)
+    ap = ARSParam("Golden", V1=V1, n_iter=iters, H=H, N=N, b=b, alpha=alpha, nu=nu,
+                  safe=False, threshold=0, initial_w="Zero")
+    agent = ARSAgent(ep, ap, seed=seed)
+    d, m = 2 * n + 2, n - 1
+    rewards = np.empty((iters, 2 * N))
+    policies = np.empty((iters, m, d))
+    means = np.zeros((iters, d))
+    covs = np.zeros((iters, d, d))
+    for it in range(iters):
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = agent.runOneIteration()
+        rewards[it] = r
+        policies[it] = agent.policy
+        if not V1:
+            means[it] = agent.mean
+            covs[it] = agent.covariance
+    out[tag + "_cfg"] = np.array([n, int(V1), N, b, H, seed, iters], dtype=np.int64)
+    out[tag + "_phys"] = np.array([l_i, m_i, k, h, alpha, nu])
+    out[tag + "_rewards"] = rewards
+    out[tag + "_policies"] = policies
+    out[tag + "_means"] = means
+    out[tag + "_covs"] = covs
+    out[tag + "_nstates"] = np.array(len(agent.saved_states), dtype=np.int64)
+
+
+def gen_more():
+    """Round 2: the chain lengths the first fixtures did not run through the reference's ARS loop
+    (n = 2: lane kernel only; n = 4, 5, 7, 8: the other instantiations of the row kernel), and
+    V2-whitened rollouts for n = 2, 4, 7, 8."""
+    out = {}
+    for case in (
+        # tag, n, pset, V1, N, b, H, alpha, nu, seed, iters
+        # n = 2 with V1: by symmetry the 2-segment swimmer never moves in y, so V2 would whiten by
+        # the variance of pure rounding noise (2e-40 in the reference) -- not a parity target
+        ("v1_n2_N4_H400", 2, "default", True, 4, 4, 400, 0.0075, 0.01, 6, 3),
+        ("v2_n4_N4_H300", 4, "realworld", False, 4, 4, 300, 0.0075, 0.01, 7, 3),
+        ("v2_n5_N3_H300", 5, "default", False, 3, 2, 300, 0.0075, 0.01, 8, 3),
+        ("v1_n7_N2_H200", 7, "odd", True, 2, 2, 200, 0.01, 0.02, 9, 3),
+        ("v2_n8_N2_H200", 8, "realworld", False, 2, 2, 200, 0.0075, 0.01, 10, 3),
+    ):
+        _ars_case(out, *case)
+    for n, pset, H in ((2, "realworld", 400), (4, "default", 400), (7, "realworld", 300), (8, "odd", 250)):
+        l_i, m_i, k, h = PARAM_SETS[pset]
+        ep = EnvParam("LeonSwimmer-Golden", n=n, H=H, l_i=l_i, m_i=m_i, h=h, k=k, epsilon=0)
+        renv = Environment(ep)
+        d, m = 2 * n + 2, n - 1
+        rs = np.random.RandomState(20 + n)
+        P = 0.05 * (2 * rs.rand(m, d) - 1)
+        mean = 0.1 * rs.randn(d)
+        mean[2::2] += np.pi / 2
+        A = rs.randn(d, d)
+        cov = 0.05 * A @ A.T + np.diag(rs.uniform(0.2, 2.0, d))
+        ret, states = renv.rollout(P, covariance=cov, mean=mean)
+        key = f"rollv2_n{n}_{pset}_H{H}"
+        out[key + "_policy"], out[key + "_mean"], out[key + "_cov"] = P, mean, cov
+        out[key + "_return"], out[key + "_traj"] = np.array(ret), np.array(states)
+    np.savez_compressed(os.path.join(OUT, "more.npz"), **out)
+    print("more.npz", len(out))
+
+
 def gen_mirrors():
     """Public methods of the reference classes that the ARS loop does not exercise in the form a
     user may call them: Environment.select_action (V1 and V2, ars/environment.py:19-35),
@@ -376,6 +439,7 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_mirrors()
     gen_long()
+    gen_more()
     gen_kat()
     gen_steps()
     gen_trajectories()

@@ -140,9 +140,9 @@ def _traj_keys(t):
 def test_rollouts_vs_reference_golden(sw, golden, kernel):
     """Both rollout kernel families: one rollout per lane ("lane") and one segment per lane
     ("quad": DPP quad for n = 3, 16-lane DPP row for n = 4..8)."""
-    t = golden.trajectories
     worst = 0.0
-    for key in _traj_keys(t):
+    for t, key in [(golden.trajectories, k) for k in _traj_keys(golden.trajectories)] + \
+                  [(golden.more, k) for k in _traj_keys(golden.more)]:
         n = int(key.split("_n")[1][0])
         if kernel == "quad" and n < 3:
             continue   # segment-per-lane kernels exist for n >= 3 (quad: n = 3, row: n = 4..8)
@@ -266,10 +266,14 @@ def cov_close(c, ref, rel):
     return bool((np.abs(c - ref) <= rel * np.outer(sd, sd)).all())
 
 
+# round 2 (tests/golden/more.npz): n = 2 (lane kernel only) and the other row-kernel instantiations
+MORE_ARS_CASES = ["v1_n2_N4_H400", "v2_n4_N4_H300", "v2_n5_N3_H300", "v1_n7_N2_H200", "v2_n8_N2_H200"]
+
+
 @pytest.mark.parametrize("kernel", ["lane", "quad"])
-@pytest.mark.parametrize("tag", ARS_CASES)
+@pytest.mark.parametrize("tag", ARS_CASES + MORE_ARS_CASES)
 def test_ars_iterations_vs_reference_golden(sw, golden, tag, kernel):
-    a = golden.ars
+    a = golden.more if tag in MORE_ARS_CASES else golden.ars
     n, V1, N, b, H, seed, iters = [int(x) for x in a[tag + "_cfg"]]
     l, m, k, h, alpha, nu = [float(x) for x in a[tag + "_phys"]]
     ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)

@@ -82,11 +82,13 @@ def test_env_module_main_scenario(golden):
 
 ARS_CASES = ["v2_n3_N4_H50", "v2_n3_N8_H50", "v2_n3_N4_H1000", "v2_n3_N6_H200_rw",
              "v1_n3_N4_H100", "v2_n6_N4_H100", "v1_n3_N1_H1000"]
+# round 2 (tests/golden/more.npz): the other chain lengths through the reference's ARS loop
+MORE_ARS_CASES = ["v1_n2_N4_H400", "v2_n4_N4_H300", "v2_n5_N3_H300", "v1_n7_N2_H200", "v2_n8_N2_H200"]
 
 
-@pytest.mark.parametrize("tag", ARS_CASES)
+@pytest.mark.parametrize("tag", ARS_CASES + MORE_ARS_CASES)
 def test_ars_iterations(golden, tag):
-    a = golden.ars
+    a = golden.more if tag in MORE_ARS_CASES else golden.ars
     n, V1, N, b, H, seed, iters = [int(x) for x in a[tag + "_cfg"]]
     l, m, k, h, alpha, nu = a[tag + "_phys"]
     o = ArsOracle(n, l, m, k, h, H, N, b, alpha, nu, bool(V1), seed)
@@ -102,6 +104,21 @@ def test_ars_iterations(golden, tag):
         if not V1:
             assert np.abs(o.mean - a[tag + "_means"][it]).max() <= 1e-9
             assert cov_close(o.covariance, a[tag + "_covs"][it], 1e-6)
+
+
+def test_more_whitened_rollouts(golden):
+    """V2-whitened 250..400-step rollouts for n = 2, 4, 7, 8 (tests/golden/more.npz)."""
+    t = golden.more
+    keys = [x[:-len("_return")] for x in t.files if x.startswith("rollv2_") and x.endswith("_return")]
+    assert len(keys) == 4
+    for key in keys:
+        n = int(key.split("_n")[1][0])
+        l, m, k, h = PARAM_SETS[key.split("_")[2]]
+        p = oracle.OracleParams.make(n, l, m, k, h)
+        ret, traj = oracle.rollout(p, t[key + "_traj"].shape[0], t[key + "_policy"], t[key + "_mean"],
+                                   t[key + "_cov"])
+        assert np.abs(traj - t[key + "_traj"]).max() <= TRAJ_TOL, key
+        assert abs(ret - float(t[key + "_return"])) <= 1e-11 * max(1.0, abs(float(t[key + "_return"]))), key
 
 
 def test_ars_training_curve(golden):
