@@ -399,7 +399,14 @@ CovTiling cov_tiling(int64_t n_roll, int32_t H, int block)
 {
     CovTiling t;
     t.nbx = (uint32_t)((n_roll + block - 1) / block);
-    const int32_t base = (block >= kMomBlock) ? kMomTChunk : kMomTChunk * (kMomBlock / block) / 2;
+    // steps per tile: long tiles for the one-wave workgroups of the quad kernel's launches -- a tile
+    // ends with a cross-lane reduction of all its accumulators, and once a batch puts a wave on
+    // every SIMD those epilogues are the rollouts' time (2048 directions on one GPU, n = 3: launch
+    // 0.2798 ms with 64 steps per tile, 0.2663 with 128, 0.384 with 32; no difference at 512
+    // directions; profiles/r02_f_cov_tile_sweep.log)
+    int32_t base = (block >= kMomBlock) ? kMomTChunk : 128;
+    static const char *env = getenv("SWIMMER_COV_TCHUNK");   // measurement knob
+    if (env && atoi(env) > 0) base = atoi(env);
     const uint32_t ny_max = (uint32_t)((H + base - 1) / base);
     const uint32_t cap = kCovMaxTiles / t.nbx > 0 ? kCovMaxTiles / t.nbx : 1u;
     const uint32_t ny = ny_max < cap ? ny_max : cap;

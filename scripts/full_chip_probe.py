@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import swimmer_amd as sw
 torch.cuda.set_stream(torch.cuda.Stream("cuda:0"))
-for n in (3, 6):
+for n in ((3, 6) if not os.environ.get('ONLY_N') else (int(os.environ['ONLY_N']),)):
     for N in (512, 2048):
-        for cov in (True, "traj-only", False):
+        for cov in (True,):
             ep = sw.EnvParam("B", n=n, H=1000, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
             ap = sw.ARSParam("B", V1=False, n_iter=0, H=1000, N=N, b=N, alpha=0.0075, nu=0.01, safe=False,
                              threshold=0, initial_w="Zero")
