@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-aux", action="store_true")
+    ap.add_argument("--collective-one-rank-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -350,36 +351,50 @@ def leg_roofline(n, n_local, H, kern_ms):
             "issue_bound": issue_bound(n, H, kern_ms)}
 
 
-def aux_collective_one_rank(sw, torch, n, H, directions, device, iters=20):
+def aux_collective_one_rank(n, H, directions, timeout=150):
     """What the per-iteration all-gather costs BEFORE any wire time: the same ARS loop with a
     one-rank RCCL process group and the collective forced (ProcessGroupNCCL + the RCCL kernel on
-    the critical stream).  The multi-GPU iteration is this plus the time on the xGMI links."""
-    import numpy as np
+    the critical stream).  The multi-GPU iteration is this plus the time on the xGMI links.
+    Runs in a CHILD process with a timeout: a communication library that fails to come up on
+    some box must not take the N = 1 line with it."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--collective-one-rank-child",
+           "--segments", str(n), "--horizon", str(H), "--directions", str(directions)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"one-rank RCCL leg did not finish in {timeout} s"}
+    lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": f"one-rank RCCL leg failed (exit code {out.returncode}): {out.stderr[-300:]}"}
+    return json.loads(lines[-1])
+
+
+def collective_one_rank_child(args):
+    """Child of aux_collective_one_rank: prints one JSON object."""
+    import torch
     import torch.distributed as dist
+    import swimmer_amd as sw
     from swimmer_amd.ars import sharding
-    state = np.random.get_state()
-    try:
-        with stdout_to_stderr():
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0,
-                                    world_size=1, device_id=torch.device(device))
-            dist.barrier()      # the communicator (and its banner) come up here at the latest
-    except Exception as exc:   # noqa: BLE001 -- reported in the line, never fatal for the N = 1 bench
-        return {"error": f"one-rank RCCL group: {exc}"}
-    try:
+    device = "cuda:0"
+    torch.cuda.set_device(0)
+    sw._lib.load()
+    with stdout_to_stderr():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0,
+                                world_size=1, device_id=torch.device(device))
+        dist.barrier()      # the communicator (and its banner) come up here at the latest
+        torch.cuda.set_stream(torch.cuda.Stream(device))
         sharding._FORCE_COLLECTIVE = True
-        leg = ArsLeg(sw, torch, n, H, directions, device)
-        with stdout_to_stderr():
-            r = leg.run(3, iters, torch.cuda.synchronize, time_every=4, postpass=16)
+        iters = 20
+        leg = ArsLeg(sw, torch, args.segments, args.horizon, args.directions, device)
+        r = leg.run(3, iters, torch.cuda.synchronize, time_every=4, postpass=16)
         leg.check(0)
-        return {"directions": directions, "ms_per_iteration": r["seconds"] / iters * 1e3,
-                "collective_us": r.get("collective_us"), "backend": dist.get_backend(),
-                "note": "one rank, all-gather forced: framework + RCCL launch cost per iteration, no wire time"}
-    except Exception as exc:   # noqa: BLE001
-        return {"error": f"{type(exc).__name__}: {exc}"}
-    finally:
-        sharding._FORCE_COLLECTIVE = False
-        np.random.set_state(state)
+        res = {"directions": args.directions, "ms_per_iteration": r["seconds"] / iters * 1e3,
+               "collective_us": r.get("collective_us"), "backend": dist.get_backend(),
+               "note": "one rank, all-gather forced: framework + RCCL launch cost per iteration, no wire time"}
         dist.destroy_process_group()
+    print(json.dumps(res), flush=True)
 
 
 def aux_ars_shard(sw, torch, n, H, directions, device, iters=12):
@@ -552,7 +567,7 @@ def run_rank(args):
                 aux["ars_2048_directions_one_gpu_n6"] = aux_ars_shard(sw, torch, 6, H, 2048, device)
             aux["shard_n3_256_directions"] = aux_ars_shard(sw, torch, 3, H, 256, device)
             aux["shard_n6_256_directions"] = aux_ars_shard(sw, torch, 6, H, 256, device)
-            aux["collective_one_rank"] = aux_collective_one_rank(sw, torch, n, H, args.directions, device)
+            aux["collective_one_rank"] = aux_collective_one_rank(n, H, args.directions)
             aux["rollout_saturated"] = aux_rollout_saturated(sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)
@@ -570,6 +585,8 @@ def run_rank(args):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse(argv)
+    if args.collective_one_rank_child:
+        return collective_one_rank_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, argv))
     run_rank(args)
