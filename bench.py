@@ -558,24 +558,31 @@ def run_rank(args):
             aux["collective_us"] = res.get("collective_us")
             if strong:
                 aux["strong_2048_directions"] = strong
-        # the step-only sweep, the shard legs and the CPU baseline belong to the N = 1 line only
+        # the step-only sweep, the shard legs and the CPU baseline belong to the N = 1 line only;
+        # none of them may take the headline numbers above with it
+        def guarded(fn, *a, **kw):
+            try:
+                return fn(*a, **kw)
+            except Exception as exc:   # noqa: BLE001 -- reported in the line
+                return {"error": f"{type(exc).__name__}: {exc}"}
+
         if not args.no_aux and world == 1:
-            aux["step_only"] = aux_step_only(sw, torch, n, device)
-            s2048 = aux_ars_shard(sw, torch, n, H, 2048, device)
-            aux["ars_2048_directions_one_gpu"] = s2048     # configs[3]'s whole problem on ONE GPU
+            aux["step_only"] = guarded(aux_step_only, sw, torch, n, device)
+            # configs[3]'s whole problem on ONE GPU
+            aux["ars_2048_directions_one_gpu"] = guarded(aux_ars_shard, sw, torch, n, H, 2048, device)
             if n != 6:   # configs[4]'s whole problem on ONE GPU (4096 rollouts = a wave on every SIMD)
-                aux["ars_2048_directions_one_gpu_n6"] = aux_ars_shard(sw, torch, 6, H, 2048, device)
-            aux["shard_n3_256_directions"] = aux_ars_shard(sw, torch, 3, H, 256, device)
-            aux["shard_n6_256_directions"] = aux_ars_shard(sw, torch, 6, H, 256, device)
-            aux["collective_one_rank"] = aux_collective_one_rank(n, H, args.directions)
-            aux["rollout_saturated"] = aux_rollout_saturated(sw, torch, device)
+                aux["ars_2048_directions_one_gpu_n6"] = guarded(aux_ars_shard, sw, torch, 6, H, 2048, device)
+            aux["shard_n3_256_directions"] = guarded(aux_ars_shard, sw, torch, 3, H, 256, device)
+            aux["shard_n6_256_directions"] = guarded(aux_ars_shard, sw, torch, 6, H, 256, device)
+            aux["collective_one_rank"] = guarded(aux_collective_one_rank, n, H, args.directions)
+            aux["rollout_saturated"] = guarded(aux_rollout_saturated, sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)
-            aux["rollout_saturated_65536"] = aux_rollout_saturated(sw, torch, device, n_roll=65536)
+            aux["rollout_saturated_65536"] = guarded(aux_rollout_saturated, sw, torch, device, n_roll=65536)
         if aux:
             line["aux"] = aux
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(n, H, args.directions, args.cpu_seconds)
+            line["cpu_baseline"] = guarded(cpu_baseline, n, H, args.directions, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
