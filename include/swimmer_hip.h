@@ -186,6 +186,13 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
                         double *acc, void *stream);
 
 
+/* ---- measurement aid ---------------------------------------------------------------------
+ * One wave issuing trips x 64 independent instructions of one class (mode 0: v_fma_f64,
+ * mode 1: v_mov_b32); scratch64: 64 doubles.  bench.py times it with HIP events to calibrate the
+ * ceiling of the latency-bound rollout kernels (one instruction per ~2 ns for a lone wave) on the
+ * device it runs on.  Replaces nothing in the reference. */
+int sw_issue_probe(int32_t mode, int32_t trips, double *scratch64, void *stream);
+
 /* ---- host helper: the reference's random stream ----------------------------------------
  * out[i] = 2*u_i - 1 with u_i the next doubles of NumPy's legacy MT19937 generator
  * (np.random.rand), continuing from the state (key[624], *pos) in the form

@@ -83,6 +83,7 @@ _PROTOTYPES = {
     "sw_traj_moments_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sw_cov_acc_doubles": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
+    "sw_issue_probe": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "sw_mt19937_uniform_pm1": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
                                               ctypes.c_int64, ctypes.c_void_p]),
     "sw_ars_pipeline_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),

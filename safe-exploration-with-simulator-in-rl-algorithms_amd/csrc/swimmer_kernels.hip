@@ -1255,6 +1255,38 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Calibration of the latency-bound rollouts' ceiling on THIS device: one wave issuing `trips` x 64
+// independent instructions of one class (mode 0: v_fma_f64 on 8 accumulators; mode 1: v_mov_b32).
+// bench.py times it with HIP events and prices the rollout kernel's per-step instruction mix
+// with the two intervals (roofline.issue_bound).
+__global__ void __launch_bounds__(kWave) issue_probe_kernel(int32_t trips, int32_t mode, double *out)
+{
+    double a0 = 1.0 + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
+           a6 = a0 + 6, a7 = a0 + 7;
+    const double m = 1.0000001, c = 1e-9;
+    int b0 = threadIdx.x, b1 = b0 + 1, b2 = b0 + 2, b3 = b0 + 3, b4 = b0 + 4, b5 = b0 + 5, b6 = b0 + 6,
+        b7 = b0 + 7;
+#define SW_FMA8 "v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n" \
+                "v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n" \
+                "v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+#define SW_MOV8 "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n" \
+                "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+    if (mode == 0) {
+        for (int32_t t = 0; t < trips; ++t)
+            asm volatile(SW_FMA8 SW_FMA8 SW_FMA8 SW_FMA8 SW_FMA8 SW_FMA8 SW_FMA8 SW_FMA8
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(m), "v"(c));
+    } else {
+        for (int32_t t = 0; t < trips; ++t)
+            asm volatile(SW_MOV8 SW_MOV8 SW_MOV8 SW_MOV8 SW_MOV8 SW_MOV8 SW_MOV8 SW_MOV8
+                         : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+    }
+#undef SW_FMA8
+#undef SW_MOV8
+    out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7);
+}
+
 // ---- dispatch on the segment count -------------------------------------------------
 #define SW_DISPATCH_N(n, CALL)                 \
     switch (n) {                               \
@@ -1381,6 +1413,16 @@ const char *sw_strerror(int code)
     case SW_ERR_LAUNCH: return "HIP kernel launch failed";
     default: return "unknown error code";
     }
+}
+
+int sw_issue_probe(int32_t mode, int32_t trips, double *scratch64, void *stream)
+{
+    (void)hipGetLastError();
+    if (!scratch64) return SW_ERR_NULL;
+    if (trips < 0 || (mode != 0 && mode != 1)) return SW_ERR_SIZE;
+    hipLaunchKernelGGL(issue_probe_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, trips, mode,
+                       scratch64);
+    return launch_status();
 }
 
 int64_t sw_moments_blocks(int64_t n_roll)

@@ -188,6 +188,28 @@ def ars_update_gathered(p: SwParams, n_dir: int, gathered, world: int, chunk: in
     return policy
 
 
+def issue_interval_ns(mode: int, device="cuda:0", trips: int = 8192):
+    """Lone-wave issue interval of one instruction class on this device (mode 0: independent
+    v_fma_f64, 1: v_mov_b32): HIP events around sw_issue_probe, nanoseconds per instruction."""
+    require_gpu()
+    scratch = torch.empty(64, dtype=torch.float64, device=device)
+    fn = load().sw_issue_probe
+    best = None
+    for _ in range(3):
+        check(fn(mode, 16, ptr(scratch), stream_ptr()), "sw_issue_probe")      # warm
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        check(fn(mode, trips, ptr(scratch), stream_ptr()), "sw_issue_probe")
+        e1.record()
+        check(fn(mode, 2 * trips, ptr(scratch), stream_ptr()), "sw_issue_probe")
+        e2.record()
+        torch.cuda.synchronize()
+        # the difference of the two launches cancels the fixed launch cost
+        ns = (e1.elapsed_time(e2) - e0.elapsed_time(e1)) * 1e6 / (trips * 64)
+        best = ns if best is None else min(best, ns)
+    return best
+
+
 def cov_acc_doubles(p: SwParams, n_roll: int, H: int) -> int:
     """Doubles in the accumulator of a covariance pass over (n_roll, H): the 1 + d + d*d sums
     followed by the pass's scratch (include/swimmer_hip.h)."""
