@@ -282,3 +282,14 @@ def test_sharded_runs_store_every_rollout(sw, tmp_path):
             j = rank * iters * per_rank + it * per_rank + local
             assert np.array_equal(ta[it * per_it + r], tb[j])
             assert np.array_equal(pa[it * per_it + r], pb[j])
+
+
+def test_issue_probe_reports_plausible_intervals(sw):
+    """sw_issue_probe (bench.py's live calibration of the lone-wave issue ceiling): an independent
+    f64 FMA and a 32-bit move issue every ~2 ns for a lone wave on MI355X."""
+    f64 = sw.kernels.issue_interval_ns(0)
+    mov = sw.kernels.issue_interval_ns(1)
+    print(f"lone-wave issue intervals: v_fma_f64 {f64:.3f} ns, v_mov_b32 {mov:.3f} ns")
+    assert 1.0 < mov < 4.0 and 1.0 < f64 < 5.0 and mov <= f64 * 1.05
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.issue_interval_ns(7)
