@@ -50,7 +50,8 @@ ROLLOUT_INSTR_PER_STEP = {3: (98, 26), 6: (214, 31)}
 # latency-bound rollout (boxes differ by ~2 % in clock, so the fraction can come out just above 1).
 LONE_WAVE_NS_F64 = 2.12
 LONE_WAVE_NS_OTHER = 1.98
-TIME_EVERY = 4                  # HIP events around every 4th rollout launch of the timed region
+TIME_EVERY = 8                  # HIP events around every 8th rollout launch of the timed region (a timed
+                                # launch costs ~10 us of pipeline bubbles: 3 samples at --steps 20)
 POSTPASS_LAUNCHES = 16          # + every launch of an untimed post-pass
 
 
