@@ -282,6 +282,75 @@ def aux_step_only(sw, torch, n, device):
     return out
 
 
+def aux_next_rows(sw, torch, device, n=3, H=1000, directions=512):
+    """SURVEY 8(f) rows either side of the hot path, measured: f-1, the estimator's objective
+    I(x) over one iteration's device-resident rollouts (one step-kernel launch over every stored
+    transition + the norm reduction); f-2, the native twin model's step kernel at a
+    bandwidth-bound batch and its rollouts on the lane kernel."""
+    import numpy as np
+    from swimmer_amd.ars.estimator import Estimator
+    out = {}
+    state = np.random.get_state()
+    ep = sw.EnvParam("LeonSwimmer-Bench", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("Bench", V1=True, n_iter=0, H=H, N=directions, b=directions, alpha=0.0075, nu=0.01,
+                     safe=False, threshold=0, initial_w="Zero")
+    agent = sw.ARSAgent(ep, ap, seed=0, device=device, record_trajectories=True)
+    agent.run_iteration_async(want_returns=False)
+    torch.cuda.synchronize()
+    est = Estimator(agent.database, ep, capacity=2 * directions, device=device)
+    est.I([1.0, 1.0, 10.0])
+    torch.cuda.synchronize()
+    reps, t0 = 20, time.perf_counter()
+    for i in range(reps):
+        est.I([1.0 + 1e-3 * i, 1.0, 10.0])      # .item() inside: host-synchronous, like CMA-ES uses it
+    dt = (time.perf_counter() - t0) / reps
+    T = 2 * directions * (H - 1)
+    out["estimator_objective"] = {"transitions": T, "us_per_evaluation": dt * 1e6,
+                                  "transitions_per_s": T / dt,
+                                  "note": "Estimator.I(x): one step-kernel launch over every stored transition "
+                                          "of a device-resident store + norm reduction + .item()"}
+    np.random.set_state(state)
+    del est, agent
+    # twin model (SW_FLAG_MODEL_TWIN): step kernel, 4 194 304 envs
+    p = sw.SwParams.make(n, 1.0, 1.0, 10.0, 0.01, flags=sw._lib.FLAG_MODEL_TWIN)
+    d, m, B = 2 * n + 2, n - 1, 1 << 22
+    rng = np.random.default_rng(0)
+    st = torch.as_tensor(rng.uniform(-1, 1, (d, B)), device=device)
+    ac = torch.as_tensor(rng.uniform(-1, 1, (m, B)), device=device)
+    nxt, rew = torch.empty_like(st), torch.empty(B, dtype=torch.float64, device=device)
+    plan = sw.kernels.StepPlan(p, st, ac, nxt, rew)
+    for _ in range(3):
+        plan.launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        plan.launch()
+    e1.record()
+    torch.cuda.synchronize()
+    per = e0.elapsed_time(e1) * 1e-3 / 10
+    byts = (2 * d + m + 1) * 8 * B
+    out["twin_step_envs_4194304"] = {"us_per_launch": per * 1e6, "env_steps_per_s": B / per,
+                                     "algorithmic_GBps": byts / per / 1e9,
+                                     "hbm_frac": byts / per / 1e9 / HBM_PEAK_GBPS}
+    del st, ac, nxt, rew, plan
+    # twin rollouts: 65 536 rollouts x H = 1000 on the lane kernel (no capture)
+    R = 65536
+    pol = torch.as_tensor(0.01 * (2 * np.random.RandomState(1).rand(4096, m, d) - 1), device=device).repeat(R // 4096, 1, 1)
+    rets = torch.empty(R, dtype=torch.float64, device=device)
+    sw.kernels.rollout(p, H, pol, returns=rets)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        sw.kernels.rollout(p, H, pol, returns=rets)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    out["twin_rollouts_65536"] = {"ms": ms, "env_steps_per_s": R * H / (ms * 1e-3),
+                                  "kernel": f"rollout_kernel<{n},false,true> (twin model, one rollout per lane)"}
+    return out
+
+
 def aux_rollout_saturated(sw, torch, device, n=3, n_roll=262144, H=1000, reps=3):
     """Where the ROLLOUT path is HBM-bound: the lane-per-rollout kernel on a batch that fills the
     chip (262 144 rollouts x H = 1000) with every post-step state captured, 16.8 GB of stores."""
@@ -597,6 +666,7 @@ def run_rank(args):
             aux["shard_n3_256_directions"] = guarded(aux_ars_shard, sw, torch, 3, H, 256, device)
             aux["shard_n6_256_directions"] = guarded(aux_ars_shard, sw, torch, 6, H, 256, device)
             aux["collective_one_rank"] = guarded(aux_collective_one_rank, n, H, args.directions)
+            aux["next_rows"] = guarded(aux_next_rows, sw, torch, device)
             aux["rollout_saturated"] = guarded(aux_rollout_saturated, sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)

@@ -23,7 +23,10 @@ class Estimator(object):
     def __init__(self, database, guess_param, capacity, unknowns=('m_i', 'l_i', 'k'),
                  device="cuda:0"):
         assert database.size > 0, "Database is empty"
-        assert len(database.trajectories[0]) == guess_param.H, "Rollouts are not the same"
+        if database._device_batches and not database._trajectories:   # still on the GPU: keep it there
+            assert database._device_batches[0][0].shape[0] == guess_param.H, "Rollouts are not the same"
+        else:
+            assert len(database.trajectories[0]) == guess_param.H, "Rollouts are not the same"
         self.guess_param = guess_param
         self.unknowns = unknowns
         self.database = database
@@ -42,11 +45,42 @@ class Estimator(object):
         ep = self.convert_to_env_param(x)
         return SwParams.make(ep.n, ep.l_i, ep.m_i, ep.k, ep.h, (1.0, 0.0))
 
+    def _batch_from_device_store(self):
+        """The same batch straight from a store that is still on the GPU (the rollout kernels'
+        [H, d, R] tensors, Database.add_device_batch): no host round trip, no per-rollout loop.
+        Transitions are grouped by iteration batch instead of by subset order (I(x) is a sum)."""
+        db = self.database
+        sizes = np.array([t.shape[2] for t, _ in db._device_batches])
+        first = np.concatenate(([0], np.cumsum(sizes)))
+        which = np.searchsorted(first, self.subset, side="right") - 1
+        S, Nx, A, lens = [], [], [], []
+        for b, (traj, pols) in enumerate(db._device_batches):
+            cols = self.subset[which == b] - first[b]
+            if cols.size == 0:
+                continue
+            idx = torch.as_tensor(cols, device=self.device)
+            tr = traj.to(self.device).index_select(2, idx)                # [H, d, c]
+            s = tr[:-1].permute(1, 2, 0).reshape(tr.shape[1], -1)           # [d, c * (H-1)], rollout-major
+            nx = tr[1:].permute(1, 2, 0).reshape(tr.shape[1], -1)
+            P = torch.as_tensor(np.ascontiguousarray(np.asarray(pols, dtype=np.float64)[cols]),
+                                device=self.device)                          # [c, m, d]
+            a = torch.einsum("cmd,tdc->mct", P, tr[:-1]).reshape(P.shape[1], -1)
+            S.append(s)
+            Nx.append(nx)
+            A.append(a)
+            lens += [tr.shape[0] - 1] * cols.size
+        return (torch.cat(S, 1).contiguous(), torch.cat(Nx, 1).contiguous(),
+                torch.cat(A, 1).contiguous(), lens)
+
     def _batch(self):
         """Device copies of the selected trajectories: states [d, T], next states [d, T],
         actions [m, T] (V1 action a = P s, estimator.py:52), segment lengths."""
         if self._cache is None:
             require_gpu()
+            db = self.database
+            if db._device_batches and not db._trajectories:
+                self._cache = self._batch_from_device_store()
+                return self._cache
             S, Nx, A, lens = [], [], [], []
             for k in self.subset:
                 P = torch.as_tensor(np.asarray(self.database.policies[k], dtype=np.float64),

@@ -293,3 +293,34 @@ def test_issue_probe_reports_plausible_intervals(sw):
     assert 1.0 < mov < 4.0 and 1.0 < f64 < 5.0 and mov <= f64 * 1.05
     with pytest.raises(sw.SwimmerHipError):
         sw.kernels.issue_interval_ns(7)
+
+
+def test_estimator_reads_a_store_that_is_still_on_the_gpu(sw):
+    """Estimator.I(x) (ars/estimator.py:36-62) over rollouts recorded by the ARS loop: the store
+    holds the rollout kernels' device tensors, and the objective is built from them without a host
+    round trip -- same value as through the reference-shaped host lists."""
+    import copy
+    from swimmer_amd.ars.estimator import Estimator
+    a = _agent(sw, N=6, H=80, seed=2, record_trajectories=True)
+    for _ in range(3):
+        a.run_iteration_async(want_returns=False)
+    torch.cuda.synchronize()
+    db = a.database
+    assert db._device_batches and not db._trajectories and db.size == 36
+    guess = sw.EnvParam("guess", n=3, H=80, l_i=0.81, m_i=1.19, h=1e-3, k=10.1, epsilon=0.01)
+    np.random.seed(1)
+    fast = Estimator(db, guess, capacity=20)
+    assert fast._batch()[0].shape == (8, 20 * 79)
+    assert db._device_batches and not db._trajectories          # nothing was materialised
+    host_db = copy.copy(db)
+    host_db._device_batches = list(db._device_batches)
+    host_db._trajectories, host_db._policies = [], []
+    host_db.materialize()
+    np.random.seed(1)
+    slow = Estimator(host_db, guess, capacity=20)
+    assert np.array_equal(fast.subset, slow.subset)
+    for x in ([1.19, 0.81, 10.1], [1.2, 0.8, 10.2], [1.0, 1.0, 9.0]):     # unknowns = (m_i, l_i, k)
+        assert fast.I(x) == pytest.approx(slow.I(x), rel=1e-12)
+    # V2 rollouts were run with whitened actions; the estimator replays V1 actions P s (the
+    # reference's estimator.py:52 does the same), so even the true parameters leave a residual
+    assert fast.I([1.2, 0.8, 10.2]) >= 0.0
