@@ -309,8 +309,34 @@ def aux_next_rows(sw, torch, device, n=3, H=1000, directions=512):
                                   "transitions_per_s": T / dt,
                                   "note": "Estimator.I(x): one step-kernel launch over every stored transition "
                                           "of a device-resident store + norm reduction + .item()"}
-    np.random.set_state(state)
     del est, agent
+    # f-3: ARS V1 and the true top-b truncation (safe_ars semantics) as options of the same loop;
+    # f-4: checkpoint save / load of a running agent
+    import tempfile
+    for tag, kw, v1 in (("ars_v1_iteration", {}, True), ("ars_top_b_64_iteration", {"top_b": 64}, False)):
+        apx = sw.ARSParam("Bench", V1=v1, n_iter=0, H=H, N=directions, b=directions, alpha=0.0075, nu=0.01,
+                          safe=False, threshold=0, initial_w="Zero")
+        ag = sw.ARSAgent(ep, apx, seed=0, device=device, **kw)
+        for _ in range(4):
+            ag.run_iteration_async(want_returns=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ag.run_iteration_async(want_returns=False)
+        torch.cuda.synchronize()
+        out[tag] = {"ms_per_iteration": (time.perf_counter() - t0) / 20 * 1e3}
+        if not v1:
+            with tempfile.TemporaryDirectory() as tmp:
+                path = os.path.join(tmp, "ck.npz")
+                t0 = time.perf_counter()
+                ag.save_checkpoint(path)
+                t1 = time.perf_counter()
+                ag.load_checkpoint(path)
+                t2 = time.perf_counter()
+                out["checkpoint"] = {"save_ms": (t1 - t0) * 1e3, "load_ms": (t2 - t1) * 1e3,
+                                     "bytes": os.path.getsize(path)}
+        del ag
+    np.random.set_state(state)
     # twin model (SW_FLAG_MODEL_TWIN): step kernel, 4 194 304 envs
     p = sw.SwParams.make(n, 1.0, 1.0, 10.0, 0.01, flags=sw._lib.FLAG_MODEL_TWIN)
     d, m, B = 2 * n + 2, n - 1, 1 << 22
