@@ -162,17 +162,37 @@ class stdout_to_stderr(object):
 
 
 # ---------------------------------------------------------------------------------------
+def kernel_source_hash():
+    """sha256 over the sources libswimmer_hip.so is built from (csrc/*.hip, *.h, *.cpp and
+    include/*.h, by sorted name).  profiles/rNN_pmc_traffic.json stores the hash of the tree its
+    PMC passes ran on (scripts/pmc_traffic_json.py), so a kernel change without a new pass shows
+    as `traffic_stale` instead of silently printing last round's bytes."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "safe-exploration-with-simulator-in-rl-algorithms_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(pkg, "*.hip")) + glob.glob(os.path.join(pkg, "*.h")) +
+                   glob.glob(os.path.join(pkg, "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, n, directions, H):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None when
-    the measured workload is not the one being benchmarked."""
+    the measured workload is not the one being benchmarked.  `stale` = the passes ran on other
+    kernel sources than the ones this run was built from."""
     if (n, directions, H) != (3, 512, 1000):
         return None
-    for name in ("r02_pmc_traffic.json", "r01_j_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_j_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
-            t = json.load(open(path)).get(kernel)
+            doc = json.load(open(path))
+            t = doc.get(kernel)
             if t:
-                return dict(t, source="profiles/" + name)
+                return dict(t, source="profiles/" + name,
+                            stale=doc.get("source_sha256") != kernel_source_hash())
     return None
 
 
@@ -223,6 +243,16 @@ def rollout_algorithmic_bytes(n, n_dir_local, H):
     return 2 * n_dir_local * H * 8 * d + 2 * n_dir_local * (8 * (n - 1) * d + 12)
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n, H, directions, seconds):
     """Time the oracle (C port of the reference step/rollout, OpenMP) on whole rollout
     batches of the benchmark's shape until `seconds` have elapsed."""
@@ -246,7 +276,7 @@ def cpu_baseline(n, H, directions, seconds):
         done += 1
     dt = time.perf_counter() - t0
     return {"value": done * 2 * directions * H / dt, "unit": "env-steps/s",
-            "cores": oracle.num_threads(), "kind": "port",
+            "cores": oracle.num_threads(), "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{done} batches of {2 * directions} rollouts x H={H} (n={n}), "
                       f"oracle/swimmer_oracle.c with OpenMP, {dt:.1f} s"}
 
@@ -279,6 +309,59 @@ def aux_step_only(sw, torch, n, device):
                     "algorithmic_GBps": byts / per / 1e9,
                     "hbm_frac": byts / per / 1e9 / HBM_PEAK_GBPS,
                     "frac_of_measured_copy_peak": byts / per / 1e9 / MEASURED_COPY_PEAK_GBPS}
+    return out
+
+
+def aux_single_env(sw, torch, device, steps=3000):
+    """The batch-1 drop-in surfaces north_star keeps: us per SwimmerEnv.step (Gym surface,
+    remy_swimmer_env.py:41-56), per bare sw_env1_step (what is under it), and per RL-Glue env_step
+    (SwimmerEnvironment.cpp:53-68) -- each ONE kernel launch + one host wait, state handed over in
+    a pinned, device-mapped block.  Beside them the reference's own CPU step, measured where the
+    reference can run (it cannot travel to the GPU box)."""
+    import ctypes
+    import numpy as np
+    out = {"reference_cpu_us_per_step": 111.0,
+           "reference_cpu_source": "SURVEY 8(d): reference Environment.rollout, 8.97e3 env-steps/s on one core of the "
+                                   "build container (scripts/time_reference_here.py); the reference cannot run on this box"}
+    env = sw.SwimmerEnv(device=device)
+    env.reset()
+    act = np.array([0.3, -0.2])
+    for _ in range(200):
+        env.step(act)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.step(act)
+    out["gym_step_us"] = (time.perf_counter() - t0) / steps * 1e6
+    h, p, K = env._env1, env._params(), sw.kernels.SingleEnv
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.step(p)
+        h.io[K.STATE:K.STATE + 8] = h.io[K.NEXT:K.NEXT + 8]
+    out["env1_step_us"] = (time.perf_counter() - t0) / steps * 1e6
+    env.close()
+
+    class Abs(ctypes.Structure):
+        _fields_ = [("numInts", ctypes.c_uint), ("numDoubles", ctypes.c_uint), ("numChars", ctypes.c_uint),
+                    ("intArray", ctypes.POINTER(ctypes.c_int)), ("doubleArray", ctypes.POINTER(ctypes.c_double)),
+                    ("charArray", ctypes.c_char_p)]
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(sw._lib.library_path()), "librlglue_swimmer_hip.so"))
+    lib.env_init.restype = ctypes.c_char_p
+    lib.env_start.restype = ctypes.c_void_p
+    lib.env_step.restype = ctypes.c_void_p
+    lib.env_step.argtypes = [ctypes.POINTER(Abs)]
+    lib.env_init()
+    lib.env_start()
+    torque = (ctypes.c_double * 2)(0.3, -0.2)
+    a = Abs(0, 2, 0, None, torque, None)
+    for _ in range(200):
+        lib.env_step(ctypes.byref(a))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lib.env_step(ctypes.byref(a))
+    out["rlglue_env_step_us"] = (time.perf_counter() - t0) / steps * 1e6
+    lib.env_cleanup()
+    out["note"] = ("one launch + one host wait per step (sw_env1_step); gym_step_us includes the Python "
+                   "list / ndarray conversions of the reference's surface")
     return out
 
 
@@ -527,6 +610,53 @@ def aux_ars_shard(sw, torch, n, H, directions, device, iters=12):
             "roofline": leg_roofline(n, directions, H, r["kernel_ms"])}
 
 
+def summary(line, aux):
+    """Flat digest of the line: one scalar per number a reader of the driver's record needs."""
+    def dig(obj, *path):
+        for k in path:
+            if not isinstance(obj, dict) or k not in obj or obj[k] is None:
+                return None
+            obj = obj[k]
+        return obj
+
+    def r3(x):
+        return None if x is None else float(f"{x:.4g}")
+
+    roof = line["roofline"]
+    out = {"n3_ms": r3(line["ms_per_step"]), "n3_sps": r3(line["value"]), "n3_kernel_ms": r3(roof.get("kernel_ms")),
+           "n3_hbm_frac": r3(roof.get("frac")), "n3_issue_frac": r3(roof.get("issue_bound_frac")),
+           "n3_instr": roof.get("instructions_per_step"), "traffic_stale": roof.get("traffic_stale")}
+    for tag, key in (("n3_sh256", "shard_n3_256_directions"), ("n6_sh256", "shard_n6_256_directions"),
+                     ("n3_2048_1gpu", "ars_2048_directions_one_gpu"), ("n6_2048_1gpu", "ars_2048_directions_one_gpu_n6")):
+        out[tag + "_ms"] = r3(dig(aux, key, "ms_per_iteration"))
+        out[tag + "_sps"] = r3(dig(aux, key, "env_steps_per_s"))
+        out[tag + "_kernel_ms"] = r3(dig(aux, key, "roofline", "kernel_ms"))
+        out[tag + "_hbm_frac"] = r3(dig(aux, key, "roofline", "frac"))
+        out[tag + "_issue_frac"] = r3(dig(aux, key, "roofline", "issue_bound", "frac"))
+        out[tag + "_over_priced"] = r3(dig(aux, key, "roofline", "issue_bound", "measured_over_priced"))
+    out.update({
+        "step8192_us": r3(dig(aux, "step_only", "envs_8192", "us_per_launch")),
+        "step8192_sps": r3(dig(aux, "step_only", "envs_8192", "env_steps_per_s")),
+        "step4m_hbm_frac": r3(dig(aux, "step_only", "envs_4194304", "hbm_frac")),
+        "sat262144_hbm_frac": r3(dig(aux, "rollout_saturated", "hbm_frac")),
+        "sat65536_hbm_frac": r3(dig(aux, "rollout_saturated_65536", "hbm_frac")),
+        "twin_step4m_hbm_frac": r3(dig(aux, "next_rows", "twin_step_envs_4194304", "hbm_frac")),
+        "coll1_us": r3(dig(aux, "collective_one_rank", "collective_us")),
+        "coll1_ms": r3(dig(aux, "collective_one_rank", "ms_per_iteration")),
+        "coll1_direct_us": r3(dig(aux, "collective_one_rank_direct", "collective_us")),
+        "coll1_direct_ms": r3(dig(aux, "collective_one_rank_direct", "ms_per_iteration")),
+        "gym_step_us": r3(dig(aux, "single_env", "gym_step_us")),
+        "env1_step_us": r3(dig(aux, "single_env", "env1_step_us")),
+        "rlglue_step_us": r3(dig(aux, "single_env", "rlglue_env_step_us")),
+        "ref_cpu_step_us": r3(dig(aux, "single_env", "reference_cpu_us_per_step")),
+        "estI_us": r3(dig(aux, "next_rows", "estimator_objective", "us_per_evaluation")),
+        "v1_ms": r3(dig(aux, "next_rows", "ars_v1_iteration", "ms_per_iteration")),
+        "topb_ms": r3(dig(aux, "next_rows", "ars_top_b_64_iteration", "ms_per_iteration")),
+        "cpu_sps": r3(dig(line, "cpu_baseline", "value")), "cpu_cores": dig(line, "cpu_baseline", "cores"),
+    })
+    return {k: v for k, v in out.items() if v is not None}
+
+
 def run_rank(args):
     import numpy as np
     import torch
@@ -627,17 +757,25 @@ def run_rank(args):
         flops_per_step = {3: 330.0, 6: 1100.0}.get(n, 40.0 * n * n)  # fp64 flop count, DESIGN.md
         traffic = pmc_traffic(rollout_kernel_name(n), n, agent.n_local, H)
         cov_alg = local_steps * 8 * d       # the ride-along covariance pass reads every state once
+        stale = bool(traffic and traffic.get("stale"))
+        ib = roof.get("issue_bound") or {}
         roof.update({
             "traffic": (traffic or {}).get("traffic_bytes"),
+            "traffic_stale": stale,     # True: the PMC passes ran on OTHER kernel sources than this build
             "traffic_breakdown": (traffic or {}).get("breakdown"),
             "traffic_source": (traffic or {}).get("source"),
+            # scalars of issue_bound once more at this level (a record that keeps scalar members only
+            # still shows what bounds the kernel)
+            "issue_bound_frac": ib.get("frac"), "issue_floor_ms": ib.get("floor_ms"),
+            "instructions_per_step": ib.get("instructions_per_step"),
+            "simd_occupancy": min(1.0, -(-2 * agent.n_local // (16 if n == 3 else 4)) / 1024.0),
             # the launch does TWO jobs: this iteration's rollouts (the bytes `achieved` counts)
             # and the covariance pass over the previous iteration's trajectories (extra
             # workgroups of the same grid).  Against the algorithmic bytes of both, the counters
             # show no wasted traffic:
             "algorithmic_bytes_with_covariance_pass": roof["algorithmic_bytes"] + cov_alg,
             "traffic_over_algorithmic": (traffic["traffic_bytes"] / (roof["algorithmic_bytes"] + cov_alg)
-                                         if traffic else None),
+                                         if traffic and not stale else None),
             "kernel_ms_timed_region": res["kernel_ms_timed_region"],
             "kernel_samples_timed_region": res["kernel_samples_timed_region"],
             "kernel_ms_postpass": res.get("kernel_ms_postpass"),
@@ -697,10 +835,15 @@ def run_rank(args):
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)
             aux["rollout_saturated_65536"] = guarded(aux_rollout_saturated, sw, torch, device, n_roll=65536)
+        if not args.no_aux and world == 1:
+            aux["single_env"] = guarded(aux_single_env, sw, torch, device)
         if aux:
             line["aux"] = aux
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = guarded(cpu_baseline, n, H, args.directions, args.cpu_seconds)
+        # LAST key, flat and short (< 1500 characters): every config's number survives a record
+        # that keeps only the tail of the line and only scalar members of its objects
+        line["summary"] = summary(line, aux)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

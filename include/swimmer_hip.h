@@ -19,6 +19,8 @@
  *   sw_ars_update_f64    ARSAgent.sort_directions / update_policy and the V2 statistics
  *                                                                   ars/ars_agent.py:97-130, :176-182
  *   sw_traj_moments_f64  np.mean / np.cov over the saved states     ars/ars_agent.py:180-182
+ *   sw_env1_step         the same step for ONE swimmer handed over in host memory (the Gym
+ *                        surface and the RL-Glue env_step, SwimmerEnvironment.cpp:53-68)
  *
  * Layouts (d = 2n+2 observation size, m = n-1 action size):
  *   state, SoA    [d][n_env]   field-major: row f holds field f of every env; fields are
@@ -42,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SW_ABI_VERSION 2
+#define SW_ABI_VERSION 3
 #define SW_MAX_SEGMENTS 8 /* kernels are instantiated for n = 2..8 */
 
 /* status codes (return values) */
@@ -141,11 +143,13 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
 /* ARS policy update + V2 statistics.
  *   returns       : [2 * n_dir] all returns of the iteration (after the all-gather)
  *   policy        : [m][d], updated in place:
- *                   P += alpha / (b * sigma_R) * sum_{i in used}(r_i+ - r_i-) delta_i
+ *                   P += alpha / (div * sigma_R) * sum_{i in used}(r_i+ - r_i-) delta_i
  *                   sigma_R = population std (ddof = 0) of the used returns.
- *   top_b         : 0 -> the reference's behaviour: every direction is used, b is only a
- *                   divisor (ars_agent.py:176-177, :126-128);  > 0 -> only the top_b
- *                   directions by max(r+, r-) are used (safe_ars/ars.py:95-96)
+ *   top_b         : 0 -> ars/ars_agent.py's behaviour: every direction is used, b is only a
+ *                   divisor (ars_agent.py:176-177, :126-128);  > 0 -> safe_ars/ars.py's
+ *                   Basic_ARS: only the top_b directions by max(r+, r-) are used (:95-96),
+ *                   sigma_R is taken over their returns (:60) and the divisor is the NUMBER OF
+ *                   DIRECTIONS USED, len(order) = min(top_b, n_dir) (:64) -- `b` is ignored
  *   moments       : NULL (V1) or [n_moment_rows][2d] partial sums of this iteration
  *   running       : NULL (V1) or [1 + 2d] statistics of every state since training began
  *                   (ars_agent.py:171, :180: never cleared): {count n, mean - c (d),
@@ -185,6 +189,33 @@ int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H);
 int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
                         double *acc, void *stream);
 
+
+/* ---- one swimmer, one step per call: the batch-1 drop-in surfaces -------------------------
+ * SwimmerEnv.step / next_observation (remy_swimmer_env.py:41-56, :69-93) and the native twin's
+ * env_step (rlglue/environment/SwimmerEnvironment.cpp:53-68) hand over ONE state and ONE action
+ * and need the next state before they return.  A handle owns a small pinned, device-mapped
+ * I/O block and a stream of its own: the caller writes state and action into the block,
+ * sw_env1_step launches ONE kernel that reads them over the bus, writes next state, reward and
+ * status back into the block and then a sequence number the host spins on -- one launch and
+ * one host wait per step; no allocation, no memcpy call, no stream synchronisation.
+ * Offsets into the block, in doubles (sized for SW_MAX_SEGMENTS): */
+#define SW_ENV1_STATE 0    /* in : [d]  observation order [Gdx, Gdy, th1, thd1, ...] */
+#define SW_ENV1_ACTION 18  /* in : [m] */
+#define SW_ENV1_NEXT 32    /* out: [d]  (sw_env1_step) */
+#define SW_ENV1_REWARD 50  /* out: [1]  (sw_env1_step) */
+#define SW_ENV1_GDD 52     /* out: [2]  (sw_env1_accel) */
+#define SW_ENV1_TDD 54     /* out: [n]  (sw_env1_accel) */
+#define SW_ENV1_DOUBLES 64
+typedef struct sw_env1 sw_env1;
+int sw_env1_create(sw_env1 **out);
+void sw_env1_destroy(sw_env1 *e);
+/* HOST pointer to the handle's I/O block (SW_ENV1_DOUBLES doubles), valid until destroy. */
+double *sw_env1_io(sw_env1 *e);
+/* One physics step of the swimmer in the block (model chosen by p->flags); BLOCKING: the
+ * outputs are in the block when it returns.  *status (host, may be NULL) receives SW_STATUS_*. */
+int sw_env1_step(sw_env1 *e, const sw_params *p, int32_t *status);
+/* compute_accelerations of the state / action in the block (remy_swimmer_env.py:95-114). */
+int sw_env1_accel(sw_env1 *e, const sw_params *p);
 
 /* ---- measurement aid ---------------------------------------------------------------------
  * One wave issuing trips x 64 independent instructions of one class (mode 0: v_fma_f64,

@@ -43,7 +43,8 @@ class ArsOracle(object):
         grad = np.zeros_like(self.policy)
         for i in order:                                            # :126-127
             grad += (r[i, 0] - r[i, 1]) * deltas[i]
-        grad /= self.b * sigma                                     # :128
+        # :128 divides by b whatever was used; safe_ars/ars.py:64 by len(order)
+        grad /= (len(order) if self.top_b > 0 else self.b) * sigma
         self.policy = self.policy + self.alpha * grad              # :130
         if not self.V1:                                            # :179-182
             states = np.concatenate(self.saved, axis=0)

@@ -12,7 +12,7 @@ import torch  # imported before the library so that both share one libamdhip64
 
 from . import _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_SEGMENTS = 8
 
 ERR_NAMES = {0: "SW_OK", 1: "SW_ERR_NULL", 2: "SW_ERR_SEGMENTS", 3: "SW_ERR_SIZE",
@@ -83,6 +83,11 @@ _PROTOTYPES = {
     "sw_traj_moments_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sw_cov_acc_doubles": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
+    "sw_env1_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "sw_env1_destroy": (None, [ctypes.c_void_p]),
+    "sw_env1_io": (ctypes.POINTER(ctypes.c_double), [ctypes.c_void_p]),
+    "sw_env1_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "sw_env1_accel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "sw_issue_probe": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "sw_mt19937_uniform_pm1": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
                                               ctypes.c_int64, ctypes.c_void_p]),

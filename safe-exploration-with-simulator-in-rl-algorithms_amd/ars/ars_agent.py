@@ -295,19 +295,31 @@ class ARSAgent(object):
 
     def save_checkpoint(self, path):
         """Everything needed to continue training bit for bit: policy, V2 running statistics,
-        covariance sums, iteration count and NumPy's global generator state.  Plain arrays
-        in an .npz (no pickle).  Collective when distributed; rank 0 writes."""
+        covariance sums (per rank when distributed), iteration count and NumPy's global generator
+        state.  Plain arrays in an .npz (no pickle).  Collective when distributed; rank 0 writes.
+        Policy, returns and V2 statistics continue bit for bit at any world size whose shards are
+        aligned to the 16-rollout moment rows; the full covariance continues bit for bit when
+        the world size is the one that saved the file (else equal up to summation order)."""
         torch.cuda.synchronize(self.device)
         kind, key, pos, has_gauss, cached = np.random.get_state()
         assert kind == "MT19937"
-        cov = None
+        cov = cov_ranks = None
         if self.full_covariance:
             self._pipe.sync_cov()
             cov = self._cov_acc[:self._cov_sums]
             if self.world > 1:
+                # every rank's own sums are kept (cov_acc_ranks): restoring them rank by rank keeps
+                # the summation order, so a resume at the same world size is bit-exact for the
+                # covariance too; cov_acc (their total) serves a resume at another world size
                 cov = cov.cpu() if dist.get_backend(self.group) == "gloo" else cov.clone()
-                dist.all_reduce(cov, group=self.group)
-            cov = cov.cpu().numpy()
+                parts = [torch.empty_like(cov) for _ in range(self.world)]
+                dist.all_gather(parts, cov, group=self.group)
+                cov_ranks = torch.stack(parts).cpu().numpy()
+                cov = cov_ranks[0].copy()
+                for r in range(1, self.world):
+                    cov += cov_ranks[r]
+            else:
+                cov = cov.cpu().numpy()
         if self.rank == 0:
             data = dict(policy=self.policy, n_saved_states=np.int64(self.n_saved_states),
                         iteration=np.int64(self._it), rng_key=key, rng_pos=np.int64(pos),
@@ -318,6 +330,8 @@ class ARSAgent(object):
                             running=self._running.cpu().numpy())
             if cov is not None:
                 data["cov_acc"] = cov
+            if cov_ranks is not None:
+                data["cov_acc_ranks"] = cov_ranks
             with open(path, "wb") as f:
                 np.savez(f, **data)
 
@@ -344,7 +358,12 @@ class ARSAgent(object):
             self._running.copy_(torch.as_tensor(running, device=dev))
         if self.full_covariance:
             self._cov_acc.zero_()
-            if "cov_acc" in z.files and self.rank == 0:   # per-rank sums add up to the total
+            if "cov_acc_ranks" in z.files and z["cov_acc_ranks"].shape[0] == self.world:
+                # same world size as the run that saved it: every rank takes its own sums back
+                self._cov_acc[:self._cov_sums].copy_(torch.as_tensor(z["cov_acc_ranks"][self.rank], device=dev))
+            elif "cov_acc" in z.files and self.rank == 0:
+                # another world size (or a one-rank file): the total goes to rank 0 -- the sums are
+                # linear, so the covariance is the same up to the order of the additions
                 self._cov_acc[:self._cov_sums].copy_(torch.as_tensor(z["cov_acc"], device=dev))
         self._cov_total_it = -1
         self.n_saved_states = int(z["n_saved_states"])

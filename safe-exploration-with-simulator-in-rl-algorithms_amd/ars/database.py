@@ -70,15 +70,34 @@ class Database(object):
             path = self.shard_path(path, rank, world)
         np.savez(path, policies=self.policies, trajectories=self.trajectories)
 
-    def load(self, path):
+    def load(self, path, world=None):
+        """The reference's single file (database.py:13-29), or -- when `path` itself does not
+        exist -- the per-rank shards save(path, rank, world) wrote.  A shard set must be complete
+        and unambiguous: exactly one world size W in the file names (or the `world` given) and
+        every rank 0 .. W-1 present; anything else raises instead of silently merging the left-overs
+        of another run into the store."""
         import glob
         import os
+        import re
         if not os.path.exists(path) and not os.path.exists(path + ".npz"):
             stem = path[:-4] if path.endswith(".npz") else path
             shards = sorted(glob.glob(glob.escape(stem) + ".rank[0-9][0-9][0-9]of[0-9][0-9][0-9].npz"))
             if shards:
+                found = {}
                 for shard in shards:
-                    self._load_one(shard)
+                    r, w = (int(v) for v in re.search(r"\.rank(\d{3})of(\d{3})\.npz$", shard).groups())
+                    found.setdefault(w, {})[r] = shard
+                if world is None:
+                    if len(found) != 1:
+                        raise ValueError(f"{stem}: shards of several runs (world sizes {sorted(found)}); "
+                                         "pass world= to choose one")
+                    world = next(iter(found))
+                ranks = found.get(int(world), {})
+                missing = [r for r in range(int(world)) if r not in ranks]
+                if missing or any(r >= int(world) for r in ranks):
+                    raise ValueError(f"{stem}: incomplete shard set for world {world}: ranks {missing} missing")
+                for r in range(int(world)):
+                    self._load_one(ranks[r])
                 return
         self._load_one(path if os.path.exists(path) else path + ".npz")
 

@@ -4,7 +4,6 @@
 // parameter file :297-326).  One swimmer, one step per call: this is the drop-in boundary
 // of the reference's native component, not a throughput path (the batched path is the C ABI
 // in swimmer_hip.h).
-#include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdio>
@@ -31,21 +30,13 @@ struct Params {
 observation_t g_obs{}, g_saved{};
 reward_observation_terminal_t g_ro{};
 std::vector<double> g_obs_buf, g_saved_buf;
-double *d_state = nullptr, *d_action = nullptr, *d_next = nullptr, *d_reward = nullptr;
+sw_env1 *g_env1 = nullptr;   // pinned, device-mapped I/O block + stream (swimmer_hip.h)
 std::string g_task_spec, g_param_msg;
 
 void fail(const char *what)
 {
     std::fprintf(stderr, "swimmer RL-Glue environment: %s\n", what);
     std::abort();
-}
-
-void hip_check(hipError_t e, const char *what)
-{
-    if (e != hipSuccess) {
-        std::fprintf(stderr, "swimmer RL-Glue environment: %s: %s\n", what, hipGetErrorString(e));
-        std::abort();
-    }
 }
 
 sw_params make_params()
@@ -64,11 +55,8 @@ sw_params make_params()
 
 void free_device()
 {
-    if (d_state) (void)hipFree(d_state);
-    if (d_action) (void)hipFree(d_action);
-    if (d_next) (void)hipFree(d_next);
-    if (d_reward) (void)hipFree(d_reward);
-    d_state = d_action = d_next = d_reward = nullptr;
+    if (g_env1) sw_env1_destroy(g_env1);
+    g_env1 = nullptr;
 }
 
 // `key value` lines (SwimmerEnvironment.cpp:297-326)
@@ -108,10 +96,7 @@ const char *env_init(void)
     g_ro.reward = 0;
     g_ro.terminal = 0;
     free_device();
-    hip_check(hipMalloc(&d_state, sizeof(double) * n_obs), "hipMalloc");
-    hip_check(hipMalloc(&d_next, sizeof(double) * n_obs), "hipMalloc");
-    hip_check(hipMalloc(&d_action, sizeof(double) * (n_action ? n_action : 1)), "hipMalloc");
-    hip_check(hipMalloc(&d_reward, sizeof(double)), "hipMalloc");
+    if (sw_env1_create(&g_env1) != SW_OK) fail("no GPU / sw_env1_create failed (there is no CPU fallback)");
     // the reference's task specification string, character for character (:30)
     g_task_spec = "VERSION RL-Glue-3.0 PROBLEMTYPE continuing DISCOUNTFACTOR 0.9 OBSERVATIONS DOUBLES (" +
                   std::to_string(n_obs) + " UNSPEC UNSPEC) ACTIONS DOUBLES (" + std::to_string(n_action) +
@@ -134,14 +119,16 @@ const reward_observation_terminal_t *env_step(const action_t *a)
         if (!(std::fabs(a->doubleArray[i]) <= g_par.max_u)) fail("action outside [-max_u, max_u]");
     const unsigned n_obs = g_obs.numDoubles, n_act = g_par.n_seg - 1;
     const sw_params p = make_params();
-    // one swimmer: SoA [d][1] is the observation vector itself
-    hip_check(hipMemcpy(d_state, g_obs.doubleArray, sizeof(double) * n_obs, hipMemcpyHostToDevice), "H2D");
-    hip_check(hipMemcpy(d_action, a->doubleArray, sizeof(double) * n_act, hipMemcpyHostToDevice), "H2D");
-    const int rc = sw_step_f64(&p, 1, d_state, d_action, d_next, d_reward, nullptr, nullptr);
+    if (!g_env1) fail("env_step before env_init");
+    // ONE launch and one host wait per step: observation and action go over in the handle's pinned,
+    // device-mapped block, which the kernel reads and writes directly (no hipMemcpy calls)
+    double *io = sw_env1_io(g_env1);
+    std::memcpy(io + SW_ENV1_STATE, g_obs.doubleArray, sizeof(double) * n_obs);
+    std::memcpy(io + SW_ENV1_ACTION, a->doubleArray, sizeof(double) * n_act);
+    const int rc = sw_env1_step(g_env1, &p, nullptr);
     if (rc != SW_OK) fail(sw_strerror(rc));
-    hip_check(hipMemcpy(g_obs.doubleArray, d_next, sizeof(double) * n_obs, hipMemcpyDeviceToHost), "D2H");
-    double r = 0.0;
-    hip_check(hipMemcpy(&r, d_reward, sizeof(double), hipMemcpyDeviceToHost), "D2H");
+    std::memcpy(g_obs.doubleArray, io + SW_ENV1_NEXT, sizeof(double) * n_obs);
+    const double r = io[SW_ENV1_REWARD];
     g_ro.observation = &g_obs;
     g_ro.reward = r;          // calculate_reward: Gdot_new . direction (:273-277)
     g_ro.terminal = 0;        // check_terminal (:279-282)

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <climits>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <utility>
 #include <vector>
@@ -86,12 +87,9 @@ sw::TwinConsts make_twin_consts(const sw_params *p)
 
 inline bool is_twin(const sw_params *p) { return (p->flags & SW_FLAG_MODEL_TWIN) != 0; }
 
-// First call of every ABI entry point.  Also drops whatever error an earlier HIP call of this
-// thread left behind (a failed call of the caller's, hipErrorNotReady from an event query, ...):
-// launch_status() must report OUR launch, not blame a stale error on it.
-int check_params(const sw_params *p)
+// Argument check shared by the entry points and the internal launchers (touches no HIP state).
+int validate_params(const sw_params *p)
 {
-    (void)hipGetLastError();
     if (!p) return SW_ERR_NULL;
     if (p->n < 2 || p->n > SW_MAX_SEGMENTS) return SW_ERR_SEGMENTS;
     if (p->flags & ~(SW_FLAG_ROLLOUT_LANE | SW_FLAG_ROLLOUT_QUAD | SW_FLAG_MODEL_TWIN)) return SW_ERR_PARAM;
@@ -99,6 +97,17 @@ int check_params(const sw_params *p)
         !isfinite(p->k) || !isfinite(p->h) || !isfinite(p->dir_x) || !isfinite(p->dir_y))
         return SW_ERR_PARAM;
     return SW_OK;
+}
+
+// First call of every PUBLIC entry point: drops, once, whatever error an earlier HIP call of this
+// thread left behind (a failed call of the caller's, hipErrorNotReady from an event query, ...), so
+// that launch_status() reports OUR launches and does not blame a stale error on them.  Internal
+// launchers use validate_params(): clearing again in the middle of an entry point would discard
+// the error of a launch the entry point itself made a moment earlier.
+int check_params(const sw_params *p)
+{
+    (void)hipGetLastError();
+    return validate_params(p);
 }
 
 // ------------------------------------------------------------------------------------
@@ -201,6 +210,72 @@ __global__ void reset_kernel(int n, int twin, int64_t n_env, double *__restrict_
     for (int i = 0; i < n; ++i) {
         state[(int64_t)(2 + 2 * i) * n_env + e] = twin ? kTwinStart : kHalfPi;
         state[(int64_t)(3 + 2 * i) * n_env + e] = twin ? kTwinStart : 0.0;
+    }
+}
+
+// One swimmer handed over in HOST memory (sw_env1, the batch-1 drop-in surfaces).  io = the
+// handle's pinned, device-mapped block (SW_ENV1_* offsets).  One wave: lane l pulls double l of
+// [state | action] -- ONE read burst over the bus instead of 25 round trips -- every lane then
+// runs the same step on broadcast copies, lane 0 posts the results and, behind a system-scope
+// fence, the sequence number the host spins on.
+template <int N, bool TWIN, bool ACCEL>
+__global__ void __launch_bounds__(kWave)
+env1_kernel(sw::Consts C, sw::TwinConsts T, double *__restrict__ io, int32_t *__restrict__ status,
+            uint32_t *__restrict__ seq_flag, uint32_t seq)
+{
+    constexpr int D = 2 * N + 2, M = N - 1;
+    const int lane = threadIdx.x;
+    const double mine = (lane < SW_ENV1_ACTION + M) ? io[lane] : 0.0;   // state 0..17, action 18..24
+    double gdx = __shfl(mine, 0, kWave), gdy = __shfl(mine, 1, kWave);
+    double th[N], thd[N], u[M > 0 ? M : 1];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        th[i] = __shfl(mine, 2 + 2 * i, kWave);
+        thd[i] = __shfl(mine, 3 + 2 * i, kWave);
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) u[i] = __shfl(mine, SW_ENV1_ACTION + i, kWave);
+    const bool in_range = sw::track_angle_range<N>(0.0, th) < sw::kAngleLimit;
+    if (ACCEL) {
+        double ax, ay, a[N];
+        if (TWIN) sw::accelerations_twin<N>(T, gdx, gdy, th, thd, u, ax, ay, a);
+        else sw::accelerations<N>(C, gdx, gdy, th, thd, u, ax, ay, a);
+        if (lane == 0) {
+            io[SW_ENV1_GDD] = in_range ? ax : __builtin_nan("");
+            io[SW_ENV1_GDD + 1] = in_range ? ay : __builtin_nan("");
+#pragma unroll
+            for (int i = 0; i < N; ++i) io[SW_ENV1_TDD + i] = in_range ? a[i] : __builtin_nan("");
+        }
+    } else {
+        double r;
+        const bool ok = TWIN ? sw::twin_step<N>(T, gdx, gdy, th, thd, u, r)
+                             : sw::euler_step<N>(C, gdx, gdy, th, thd, u, r);
+        if (!in_range) {
+            gdx = gdy = r = __builtin_nan("");
+#pragma unroll
+            for (int i = 0; i < N; ++i) th[i] = thd[i] = __builtin_nan("");
+        }
+        bool fin = isfinite(gdx) && isfinite(gdy);
+#pragma unroll
+        for (int i = 0; i < N; ++i) fin = fin && isfinite(th[i]) && isfinite(thd[i]);
+        if (lane == 0) {
+            io[SW_ENV1_NEXT] = gdx;
+            io[SW_ENV1_NEXT + 1] = gdy;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                io[SW_ENV1_NEXT + 2 + 2 * i] = th[i];
+                io[SW_ENV1_NEXT + 3 + 2 * i] = thd[i];
+            }
+            io[SW_ENV1_REWARD] = r;
+            *status = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE) |
+                      (in_range ? 0 : SW_STATUS_RANGE);
+        }
+    }
+    static_assert(D <= SW_ENV1_ACTION && SW_ENV1_ACTION + M <= SW_ENV1_NEXT && SW_ENV1_NEXT + D <= SW_ENV1_REWARD,
+                  "I/O block layout");
+    if (lane == 0) {
+        __threadfence_system();   // the results are visible to the host before the sequence number is
+        __hip_atomic_store(seq_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1183,7 +1258,10 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         block_sum2(v, g, sh2);
         if (threadIdx.x == 0) {
             const double sigma = sqrt(v / cnt);
-            const double grad = g / (b * sigma);            // ars_agent.py:128
+            // divisor: b as given (ars_agent.py:128: all directions used, b only divides), or with
+            // a true top-b truncation the number of directions used, len(order) (safe_ars/ars.py:64)
+            const double div = (top_b > 0) ? 0.5 * cnt : b;
+            const double grad = g / (div * sigma);
             policy[e] = policy[e] + alpha * grad;           // ars_agent.py:130
             if (e == 0 && sigma_out) *sigma_out = sigma;
         }
@@ -1548,7 +1626,7 @@ static int launch_ars_rollouts(const sw_params *p, int64_t dir_begin, int64_t n_
                                double *traj, double *moments, int32_t *status, void *stream,
                                const SideJob *side, bool *side_taken)
 {
-    int rc = check_params(p);
+    int rc = validate_params(p);   // the public entry points have cleared stale errors already
     if (rc) return rc;
     if (n_dir < 0 || H < 0 || dir_begin < 0) return SW_ERR_SIZE;
     if (side_taken) *side_taken = false;
@@ -1602,6 +1680,7 @@ int sw_ars_rollouts_f64(const sw_params *p, int64_t dir_begin, int64_t n_dir, in
                         const double *inv_std, double *returns, double *traj, double *moments,
                         int32_t *status, void *stream)
 {
+    (void)hipGetLastError();   // public entry point: drop a stale error once (see check_params)
     return launch_ars_rollouts(p, dir_begin, n_dir, H, policy, deltas, nu, mean, inv_std, returns,
                                traj, moments, status, stream, nullptr, nullptr);
 }
@@ -1683,7 +1762,7 @@ static int launch_traj_moments(const sw_params *p, int64_t n_roll, int32_t H, co
 
 int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H)
 {
-    if (check_params(p) != SW_OK || n_roll < 0 || H < 0) return -1;
+    if (validate_params(p) != SW_OK || n_roll < 0 || H < 0) return -1;   // pure host arithmetic
     const int d = 2 * p->n + 2;
     int64_t tiles = 0;
     if (n_roll > 0 && H > 0) {
@@ -1701,6 +1780,89 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
     if (rc) return rc;
     return launch_traj_moments(p, n_roll, H, traj, acc, kMomBlock, stream);
 }
+
+// ---- one swimmer per call (include/swimmer_hip.h, sw_env1) -----------------------------
+struct sw_env1 {
+    double *io_host = nullptr, *io_dev = nullptr;   // SW_ENV1_DOUBLES doubles + {status, seq}
+    hipStream_t stream = nullptr;
+    uint32_t seq = 0;
+};
+
+int sw_env1_create(sw_env1 **out)
+{
+    if (!out) return SW_ERR_NULL;
+    sw_env1 *e = new (std::nothrow) sw_env1();
+    if (!e) return SW_ERR_LAUNCH;
+    const size_t bytes = sizeof(double) * SW_ENV1_DOUBLES + 64;
+    bool ok = hipHostMalloc((void **)&e->io_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) {
+        memset(e->io_host, 0, bytes);
+        ok = hipHostGetDevicePointer((void **)&e->io_dev, e->io_host, 0) == hipSuccess &&
+             hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+    }
+    if (!ok) {
+        sw_env1_destroy(e);
+        return SW_ERR_LAUNCH;
+    }
+    *out = e;
+    return SW_OK;
+}
+
+void sw_env1_destroy(sw_env1 *e)
+{
+    if (!e) return;
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamDestroy(e->stream);
+    }
+    if (e->io_host) (void)hipHostFree(e->io_host);
+    delete e;
+}
+
+double *sw_env1_io(sw_env1 *e) { return e ? e->io_host : nullptr; }
+
+static int env1_run(sw_env1 *e, const sw_params *p, bool accel, int32_t *status)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!e) return SW_ERR_NULL;
+    const sw::Consts C = make_consts(p);
+    const sw::TwinConsts T = make_twin_consts(p);
+    int32_t *st_host = reinterpret_cast<int32_t *>(e->io_host + SW_ENV1_DOUBLES);
+    int32_t *st_dev = reinterpret_cast<int32_t *>(e->io_dev + SW_ENV1_DOUBLES);
+    const volatile uint32_t *flag_host = reinterpret_cast<const volatile uint32_t *>(st_host + 1);
+    uint32_t *flag_dev = reinterpret_cast<uint32_t *>(st_dev + 1);
+    const uint32_t seq = ++e->seq;
+#define SW_ENV1_LAUNCH(TW, AC)                                                                     \
+    SW_DISPATCH_N(p->n, hipLaunchKernelGGL((env1_kernel<NN, TW, AC>), dim3(1), dim3(kWave), 0,     \
+                                           e->stream, C, T, e->io_dev, st_dev, flag_dev, seq))
+    if (is_twin(p)) {
+        if (accel) { SW_ENV1_LAUNCH(true, true); } else { SW_ENV1_LAUNCH(true, false); }
+    } else {
+        if (accel) { SW_ENV1_LAUNCH(false, true); } else { SW_ENV1_LAUNCH(false, false); }
+    }
+#undef SW_ENV1_LAUNCH
+    rc = launch_status();
+    if (rc) return rc;
+    for (int64_t spins = 0; *flag_host != seq; ++spins) {
+        if ((spins & 0xffff) == 0xffff) {
+            // not hot any more: a stream that has drained without the flag moving has failed
+            const hipError_t q = hipStreamQuery(e->stream);
+            if (q == hipSuccess) {
+                if (*flag_host == seq) break;
+                return SW_ERR_LAUNCH;
+            }
+            if (q != hipErrorNotReady) return SW_ERR_LAUNCH;
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (status) *status = accel ? 0 : *st_host;
+    return SW_OK;
+}
+
+int sw_env1_step(sw_env1 *e, const sw_params *p, int32_t *status) { return env1_run(e, p, false, status); }
+int sw_env1_accel(sw_env1 *e, const sw_params *p) { return env1_run(e, p, true, nullptr); }
 
 // ---- ARS iteration pipeline ---------------------------------------------------------
 // Host-side enqueue logic of one ARS iteration in native code: the caller's stream (the
@@ -1946,6 +2108,8 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
     if (!quad && !row) {
         // the lane kernel takes no side job: the flag as a launch of its own in front of it
         hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, main, pl->flag_dev, k);
+        rc = launch_status();   // a failed flag launch must surface here, not iterations later in wait_flag
+        if (rc) return rc;
         sj = kNoSide;
     }
     rc = launch_ars_rollouts(p, dir_begin, n_dir, H, policy, deltas_dev, nu, mean, inv_std,

@@ -126,24 +126,30 @@ class SwimmerEnv(object):
         self.observation_space = Box(-1000, 1000, (2 * n + 2,))
         self.action_space = Box(-max_u, max_u, (n - 1,))
         self.device = torch.device(device)
-        self._status = None
+        self._env1 = None   # kernels.SingleEnv, created on first use
+        self._dev_index = self.device.index or 0
 
     # parameters are plain attributes in the reference and may be reassigned between
     # calls (ars/estimator.py builds envs per candidate), so the struct is rebuilt lazily
     def _params(self):
         return SwParams.make(self.n, self.l_i, self.m_i, self.k, self.h, self.direction)
 
-    def _soa(self, G_dot, theta, theta_dot):
-        s = np.empty(2 * self.n + 2)
-        s[0:2] = G_dot
-        s[2::2] = theta
-        s[3::2] = theta_dot
-        return torch.as_tensor(s.reshape(-1, 1), device=self.device)
-
-    def _act(self, torque):
-        a = np.ascontiguousarray(torque, dtype=np.float64).reshape(-1)
+    def _handover(self, torque, G_dot, theta, theta_dot):
+        """State and action into the handle's host-mapped I/O block (kernels.SingleEnv)."""
+        require_gpu()
+        if self._env1 is None:
+            with torch.cuda.device(self.device):   # the handle's stream lives on this device
+                self._env1 = kernels.SingleEnv()
+        if torch.cuda.current_device() != self._dev_index:
+            torch.cuda.set_device(self._dev_index)
+        a = np.asarray(torque, dtype=np.float64).reshape(-1)
         assert a.shape[0] == self.n - 1, f"Action {torque} has not the right dimension"
-        return torch.as_tensor(a.reshape(-1, 1), device=self.device)
+        io, d = self._env1.io, 2 * self.n + 2
+        io[0:2] = G_dot
+        io[2:d:2] = theta
+        io[3:d:2] = theta_dot
+        io[kernels.SingleEnv.ACTION:kernels.SingleEnv.ACTION + self.n - 1] = a
+        return io, d
 
     def reset(self):
         self.G_dot = np.full(2, 0.)
@@ -161,20 +167,21 @@ class SwimmerEnv(object):
         return ob, reward, done, info
 
     def next_observation(self, torque, G_dot, theta, theta_dot):
-        require_gpu()
-        if self._status is None:
-            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        nxt, _ = kernels.step(self._params(), self._soa(G_dot, theta, theta_dot),
-                              self._act(torque), status=self._status)
-        s = nxt.reshape(-1).cpu().numpy()
-        _raise_if_singular(self._status)
+        """remy_swimmer_env.py:69-93 for one swimmer: ONE kernel launch and one host wait per call
+        (sw_env1_step: state and action go over in a pinned, device-mapped block the kernel reads
+        and writes directly -- no tensors, no copies, no stream synchronisation)."""
+        io, d = self._handover(torque, G_dot, theta, theta_dot)
+        status = self._env1.step(self._params())
+        if status & STATUS_SINGULAR:
+            raise np.linalg.LinAlgError("Singular matrix")
+        s = io[kernels.SingleEnv.NEXT:kernels.SingleEnv.NEXT + d]
         return s[0:2].copy(), s[2::2].copy(), s[3::2].copy()
 
     def compute_accelerations(self, torque, G_dot, theta, theta_dot):
-        require_gpu()
-        gdd, tdd = kernels.accelerations(self._params(), self._soa(G_dot, theta, theta_dot),
-                                         self._act(torque))
-        return gdd.reshape(-1).cpu().numpy(), tdd.reshape(-1).cpu().numpy()
+        io, _ = self._handover(torque, G_dot, theta, theta_dot)
+        self._env1.accelerations(self._params())
+        K = kernels.SingleEnv
+        return io[K.GDD:K.GDD + 2].copy(), io[K.TDD:K.TDD + self.n].copy()
 
     def get_state(self):
         ob = self.G_dot.tolist()
@@ -200,4 +207,7 @@ class SwimmerEnv(object):
         return
 
     def close(self):
+        if self._env1 is not None:
+            self._env1.close()
+            self._env1 = None
         return None

@@ -68,6 +68,49 @@ class StepPlan(object):
             check(rc, "sw_step_f64")
 
 
+class SingleEnv(object):
+    """sw_env1: ONE swimmer handed over in host memory -- the batch-1 surface under
+    `SwimmerEnv.step` (remy_swimmer_env.py:41-56).  The handle owns a pinned, device-mapped I/O
+    block; `io` is a NumPy view of it (offsets SW_ENV1_* of include/swimmer_hip.h).  A step is
+    one kernel launch and one host wait: no tensor is created, nothing is copied by a call."""
+    STATE, ACTION, NEXT, REWARD, GDD, TDD, DOUBLES = 0, 18, 32, 50, 52, 54, 64
+
+    def __init__(self):
+        require_gpu()
+        import numpy as np
+        lib = load()
+        h = ctypes.c_void_p()
+        check(lib.sw_env1_create(ctypes.byref(h)), "sw_env1_create")
+        self._h, self._lib = h, lib
+        self.io = np.ctypeslib.as_array(lib.sw_env1_io(h), shape=(self.DOUBLES,))
+        self._status = ctypes.c_int32(0)
+        self._step, self._accel = lib.sw_env1_step, lib.sw_env1_accel
+
+    def step(self, p: SwParams):
+        """State and action are in `io`; returns the status bits, next state / reward in `io`."""
+        rc = self._step(self._h, ctypes.byref(p), ctypes.byref(self._status))
+        if rc:
+            check(rc, "sw_env1_step")
+        return self._status.value
+
+    def accelerations(self, p: SwParams):
+        rc = self._accel(self._h, ctypes.byref(p))
+        if rc:
+            check(rc, "sw_env1_accel")
+
+    def close(self):
+        if self._h is not None:
+            self.io = None
+            self._lib.sw_env1_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 def accelerations(p: SwParams, state, action):
     """SwimmerEnv.compute_accelerations -> (Gdd [2, n_env], thdd [n, n_env])."""
     require_gpu()

@@ -432,11 +432,108 @@ def gen_long():
     print("long.npz: mean return first / last", curve[0], curve[-1], "max", curve.max())
 
 
+def _load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_next_rows():
+    """Round 3: the two "next" rows that rested on hand restatements.
+
+    (a) safe_ars/ars.py Basic_ARS.train (:67-98): true top-b truncation (`order[:b]`, :96), sigma_R
+        over the used returns (:57-60) and the divisor len(order) (:64).  `train` keeps no
+        per-iteration policy, so it is run for n_iter = 1, 2, 3, ... from the same seed (the delta
+        stream of a shorter run is a prefix of the longer one); the per-rollout returns of every
+        iteration come from a replay through the reference's own rollout / sort_directions /
+        update_policy methods on the same stream (checked here against train's all_returns).
+    (b) ars/estimator.py Estimator.I (:36-62) and J (:64-87) on a Database of reference rollouts
+        (ars/database.py:31-34), with the `subset` the constructor drew (:33)."""
+    out = {}
+    arsmod = _load_by_path("ref_safe_ars", "safe_ars/ars.py")
+    cases = (
+        # tag, n, pset, N, b, H, alpha, nu, seed, iters
+        ("basic_n3_N8_b3", 3, "default", 8, 3, 80, 0.01, 0.02, 4, 3),
+        ("basic_n3_N4_b6", 3, "realworld", 4, 6, 120, 0.0075, 0.01, 5, 2),   # b > N: len(order) = N
+        ("basic_n6_N4_b2", 6, "default", 4, 2, 100, 0.01, 0.02, 6, 2),
+    )
+    for tag, n, pset, N, b, H, alpha, nu, seed, iters in cases:
+        d, m = 2 * n + 2, n - 1
+        pols = np.empty((iters, m, d))
+        curves = []
+        for k in range(1, iters + 1):
+            agent = arsmod.Basic_ARS()
+            np.random.seed(seed)
+            with contextlib.redirect_stdout(io.StringIO()):
+                curve, states = agent.train(k, make_env(n, pset), N, b, alpha, nu, H)
+            pols[k - 1] = agent.policy
+            curves.append(curve)
+        assert all(np.array_equal(curves[-1][:len(c)], c) for c in curves)
+        # replay with the reference's own methods for the per-rollout returns and the orders
+        agent = arsmod.Basic_ARS()
+        env = make_env(n, pset)
+        np.random.seed(seed)
+        agent.policy = np.zeros((m, d))
+        rets = np.empty((iters, 2 * N))
+        orders = np.full((iters, N), -1, dtype=np.int64)
+        for it in range(iters):
+            deltas = [2 * np.random.rand(m, d) - 1 for _ in range(N)]
+            r = []
+            for i in range(N):
+                r.append(agent.rollout(env, agent.policy + nu * deltas[i], H)[0])
+                r.append(agent.rollout(env, agent.policy - nu * deltas[i], H)[0])
+            order = agent.sort_directions(deltas, r)[:b]
+            agent.update_policy(deltas, r, order, alpha)
+            rets[it] = r
+            orders[it, :len(order)] = order
+            assert np.array_equal(agent.policy, pols[it]) and np.mean(r) == curves[-1][it]
+        out[tag + "_cfg"] = np.array([n, N, b, H, seed, iters], dtype=np.int64)
+        l_i, m_i, k_, h = PARAM_SETS[pset]
+        out[tag + "_phys"] = np.array([l_i, m_i, k_, h, alpha, nu])
+        out[tag + "_policies"] = pols
+        out[tag + "_curve"] = np.array(curves[-1])
+        out[tag + "_returns"] = rets
+        out[tag + "_orders"] = orders
+        out[tag + "_last_states_shape"] = np.array(np.shape(states), dtype=np.int64)
+        out[tag + "_last_state"] = np.array(states[-1][-1])
+
+    # (b) estimator objectives
+    from ars.database import Database
+    from ars.estimator import Estimator
+    H = 60
+    l_i, m_i, k_, h = PARAM_SETS["realworld"]
+    real = EnvParam("real world", n=3, H=H, l_i=l_i, m_i=m_i, h=h, k=k_, epsilon=0)
+    renv = Environment(real)
+    db = Database()
+    rs = np.random.RandomState(31)
+    for _ in range(3):
+        P = 0.2 * (2 * rs.rand(2, 8) - 1)
+        _, states = renv.rollout(P)          # V1 interaction (estimator.py:77)
+        db.add_trajectory(states, P)
+    guess = EnvParam("Simulator with estimation", n=3, H=H, m_i=1.01, l_i=1.01, h=h, k=10.01,
+                     epsilon=0.01)
+    np.random.seed(12)
+    est = Estimator(db, guess, capacity=4)
+    xs = np.array([[m_i, l_i, k_], [1.01, 1.01, 10.01], [0.9, 1.2, 9.0]])   # unknowns (m_i, l_i, k)
+    out["est_policies"] = np.array(db.policies)
+    out["est_trajectories"] = np.array(db.trajectories)
+    out["est_subset"] = np.array(est.subset, dtype=np.int64)
+    out["est_guess"] = np.array([1.01, 1.01, 10.01, h])          # m_i, l_i, k, h
+    out["est_x"] = xs
+    out["est_I"] = np.array([est.I(x) for x in xs])
+    out["est_J"] = np.array([est.J(x) for x in xs])
+    assert out["est_I"][0] == 0.0            # the reference's own check (estimator.py:138)
+    np.savez_compressed(os.path.join(OUT, "next_rows.npz"), **out)
+    print("next_rows.npz", len(out), "I", out["est_I"], "J", out["est_J"])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # e.g. `make_golden.py mirrors long`: only these files
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
         sys.exit(0)
+    gen_next_rows()
     gen_mirrors()
     gen_long()
     gen_more()

@@ -31,7 +31,8 @@ def test_header_declares_the_expected_entry_points():
                  "sw_accel_f64", "sw_reset_f64", "sw_traj_moments_f64", "sw_strerror",
                  "sw_abi_version", "sw_ars_update_gathered_f64", "sw_ars_pipeline_create",
                  "sw_ars_iteration_rollouts_f64", "sw_ars_iteration_update_f64",
-                 "sw_mt19937_uniform_pm1"):
+                 "sw_mt19937_uniform_pm1", "sw_env1_create", "sw_env1_step", "sw_env1_accel",
+                 "sw_env1_io", "sw_env1_destroy"):
         assert must in names
 
 
@@ -40,7 +41,7 @@ def test_library_exports_every_declared_symbol(sw):
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/swimmer_hip.h but not exported"
     assert set(sw._lib.EXPORTED_SYMBOLS) == set(declared_functions())
-    assert sw._lib.load().sw_abi_version() == 2
+    assert sw._lib.load().sw_abi_version() == 3
     assert sw._lib.load().sw_max_segments() == 8
 
 
@@ -66,6 +67,10 @@ def test_argument_validation_needs_no_gpu(sw):
     assert lib.sw_rollout_f64(None, 1, 1, *([None] * 10)) == 1
     assert lib.sw_moments_blocks(0) == 0 and lib.sw_moments_blocks(65) == 5   # one row per 16 rollouts
     assert lib.sw_strerror(2).decode().startswith("number of segments")
+    # the batch-1 surface validates before it touches a handle or the device
+    assert lib.sw_env1_step(None, ctypes.byref(bad_n), None) == 2
+    assert lib.sw_env1_step(None, ctypes.byref(ok), None) == 1
+    assert lib.sw_env1_create(None) == 1
 
 
 def test_compute_fails_loudly_without_gpu(sw):

@@ -1,0 +1,60 @@
+"""bench.py's record-keeping (no GPU): the flat `summary` object the driver's record keeps, and the
+tie between `roofline.traffic` and the kernel sources the PMC passes ran on."""
+import json
+import os
+
+import bench
+from conftest import ROOT
+
+
+def test_summary_is_flat_short_and_last():
+    shard = {"ms_per_iteration": 0.5123456, "env_steps_per_s": 1.23456789e9,
+             "roofline": {"kernel_ms": 0.50123, "frac": 0.014321,
+                          "issue_bound": {"frac": 0.93123, "measured_over_priced": 1.3061}}}
+    aux = {k: shard for k in ("shard_n3_256_directions", "shard_n6_256_directions",
+                              "ars_2048_directions_one_gpu", "ars_2048_directions_one_gpu_n6")}
+    aux.update(step_only={"envs_8192": {"us_per_launch": 3.2123, "env_steps_per_s": 2.5e9},
+                          "envs_4194304": {"hbm_frac": 0.6912}},
+               rollout_saturated={"hbm_frac": 0.6171}, rollout_saturated_65536={"hbm_frac": 0.7172},
+               next_rows={"twin_step_envs_4194304": {"hbm_frac": 0.683},
+                          "estimator_objective": {"us_per_evaluation": 127.04},
+                          "ars_v1_iteration": {"ms_per_iteration": 0.2301},
+                          "ars_top_b_64_iteration": {"ms_per_iteration": 0.2931}},
+               collective_one_rank={"collective_us": 16.12, "ms_per_iteration": 0.27231},
+               collective_one_rank_direct={"collective_us": 9.12, "ms_per_iteration": 0.26831},
+               single_env={"gym_step_us": 25.01, "env1_step_us": 12.02, "rlglue_env_step_us": 13.03,
+                           "reference_cpu_us_per_step": 111.0})
+    line = {"ms_per_step": 0.260212, "value": 3.9351e9,
+            "roofline": {"kernel_ms": 0.25231, "frac": 0.03251, "issue_bound_frac": 0.951,
+                         "instructions_per_step": 124, "traffic_stale": False},
+            "cpu_baseline": {"value": 5.22e7, "cores": 16}}
+    sm = bench.summary(line, aux)
+    assert all(isinstance(v, (int, float, bool)) for v in sm.values())      # scalars only
+    assert len(json.dumps(sm)) < 1500
+    for key in ("n6_sh256_ms", "n6_sh256_sps", "n6_sh256_hbm_frac", "n6_sh256_issue_frac", "n3_sh256_ms",
+                "n3_2048_1gpu_ms", "n6_2048_1gpu_over_priced", "step8192_us", "step4m_hbm_frac",
+                "sat262144_hbm_frac", "sat65536_hbm_frac", "coll1_us", "gym_step_us", "rlglue_step_us"):
+        assert key in sm
+    # a leg that failed ({"error": ...}) drops its keys instead of raising
+    aux["shard_n6_256_directions"] = {"error": "boom"}
+    assert "n6_sh256_ms" not in bench.summary(line, aux)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('line["summary"] = summary(line, aux)') > src.index('line["cpu_baseline"]')
+
+
+def test_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    h = bench.kernel_source_hash()
+    assert len(h) == 64 and h == bench.kernel_source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    kern = bench.rollout_kernel_name(3)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: h)
+    (prof / "r03_pmc_traffic.json").write_text(json.dumps({"source_sha256": h, kern: {"traffic_bytes": 7}}))
+    t = bench.pmc_traffic(kern, 3, 512, 1000)
+    assert t["traffic_bytes"] == 7 and t["stale"] is False
+    (prof / "r03_pmc_traffic.json").write_text(json.dumps({"source_sha256": "0" * 64, kern: {"traffic_bytes": 7}}))
+    assert bench.pmc_traffic(kern, 3, 512, 1000)["stale"] is True
+    (prof / "r03_pmc_traffic.json").write_text(json.dumps({kern: {"traffic_bytes": 7}}))   # no hash recorded
+    assert bench.pmc_traffic(kern, 3, 512, 1000)["stale"] is True
+    assert bench.pmc_traffic(kern, 3, 256, 1000) is None           # another workload than the measured one

@@ -119,17 +119,90 @@ def test_known_answers(sw, golden):
 
 
 def test_gym_surface_step_for_step(sw, golden):
-    """Drive the Gym-style env exactly like the reference's __main__ (seed-23 scenario)."""
+    """BASELINE configs[0]: drive the Gym-style env exactly like the reference's __main__ (seed-23
+    scenario, remy_swimmer_env.py:301-316) for all 1000 recorded steps -- one sw_env1_step launch
+    per call, state handed over and back through the host-mapped block."""
     t = golden.trajectories
     env = sw.SwimmerEnv()
     env.set_state(t["main23_state0"].tolist())
-    total = 0.0
-    for i in range(200):
-        ob, r, done, _ = env.step(np.zeros(2))
-        assert isinstance(ob, list) and len(ob) == 8 and done is False
-        assert np.abs(np.array(ob) - t["main23_traj"][i]).max() <= 1e-11
-        assert abs(r - t["main23_rewards"][i]) <= 1e-12
+    total, worst = 0.0, 0.0
+    for i in range(1000):
+        ob, r, done, info = env.step(np.zeros(2))
+        assert isinstance(ob, list) and len(ob) == 8 and done is False and info == {}
+        worst = max(worst, np.abs(np.array(ob) - t["main23_traj"][i]).max())
+        assert abs(r - t["main23_rewards"][i]) <= 1e-11
         total += r
+    assert worst <= 1e-10                       # contract: 1e-5
+    assert abs(total - float(t["main23_total_seq"])) <= 1e-9 * abs(float(t["main23_total_seq"]))
+    assert abs(total - 756.1082843556578) < 1e-6   # SURVEY App. C anchor
+    env.close()
+    with pytest.raises(AssertionError):          # wrong action length, like the reference's check
+        sw.SwimmerEnv().step([0.0])
+
+
+def test_single_env_handle_matches_the_batched_step(sw, golden):
+    """sw_env1_step / sw_env1_accel (the kernels under SwimmerEnv.step and the RL-Glue env_step)
+    against the batched sw_step_f64 / sw_accel_f64 on the same inputs: bit for bit, n = 2..8, both
+    models; status bits come back through the block."""
+    g = golden.steps
+    h = sw.kernels.SingleEnv()
+    K = sw.kernels.SingleEnv
+    for n in (2, 3, 4, 5, 6, 8):
+        for flags in (0, sw._lib.FLAG_MODEL_TWIN):
+            p = sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3 if not flags else 0.01, (0.6, -0.8), flags=flags)
+            key = f"n{n}_realworld"
+            st, ac = g[key + "_state"][:6], g[key + "_action"][:6]
+            nxt, rew = sw.kernels.step(p, soa(st), soa(ac))
+            gdd, tdd = sw.kernels.accelerations(p, soa(st), soa(ac))
+            nxt, rew, gdd, tdd = nxt.T.cpu().numpy(), rew.cpu().numpy(), gdd.T.cpu().numpy(), tdd.T.cpu().numpy()
+            for b in range(6):
+                h.io[K.STATE:K.STATE + p.d] = st[b]
+                h.io[K.ACTION:K.ACTION + p.m] = ac[b]
+                assert h.step(p) == 0
+                assert np.array_equal(h.io[K.NEXT:K.NEXT + p.d], nxt[b])
+                assert h.io[K.REWARD] == rew[b]
+                h.accelerations(p)
+                assert np.array_equal(h.io[K.GDD:K.GDD + 2], gdd[b])
+                assert np.array_equal(h.io[K.TDD:K.TDD + n], tdd[b])
+    p = sw.SwParams.make(3)
+    h.io[K.STATE:K.STATE + 8] = [0, 0, 4e9, 0, 1, 0, 1, 0]       # beyond the in-kernel sin / cos range
+    h.io[K.ACTION:K.ACTION + 2] = 0
+    assert h.step(p) & sw._lib.STATUS_RANGE and np.isnan(h.io[K.NEXT:K.NEXT + 8]).all()
+    h.close()
+
+
+def test_quad_eligible_batch_with_a_4gib_trajectory_buffer(sw):
+    """The quad kernel addresses the trajectory buffer with 32-bit byte offsets; a batch it would
+    otherwise take (n = 3, 16 384 rollouts) whose buffer reaches 4 GiB (H = 4096) must fall back to
+    the lane kernel -- also when the caller FORCES the quad kernel -- and so give the lane kernel's
+    bits, with every step landing where the layout says."""
+    n, R, H = 3, 16384, 4096
+    rs = np.random.RandomState(3)
+    pol = torch.as_tensor(0.05 * (2 * rs.rand(64, 2, 8) - 1), device="cuda:0").repeat(R // 64, 1, 1).contiguous()
+    out = {}
+    for name, flags in (("lane", sw._lib.FLAG_ROLLOUT_LANE), ("auto", 0), ("quad", sw._lib.FLAG_ROLLOUT_QUAD)):
+        p = sw.SwParams.make(n, flags=flags)
+        traj = torch.full((H, 8, R), float("nan"), dtype=torch.float64, device="cuda:0")
+        assert traj.numel() * 8 == 1 << 32
+        fin = torch.empty((8, R), dtype=torch.float64, device="cuda:0")
+        status = torch.zeros(R, dtype=torch.int32, device="cuda:0")
+        ret = sw.kernels.rollout(p, H, pol, traj=traj, final_state=fin, status=status)
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0
+        assert torch.equal(traj[H - 1], fin) and not torch.isnan(traj[::511]).any()
+        out[name] = (ret.cpu().numpy(), traj[H - 1].cpu().numpy(), traj[1000, :, ::97].cpu().numpy())
+        del traj
+        torch.cuda.empty_cache()
+    for name in ("auto", "quad"):
+        for a, b in zip(out[name], out["lane"]):
+            assert np.array_equal(a, b)
+    # one step below the limit the quad kernel does run (different summation order: not the lane bits)
+    p = sw.SwParams.make(n, flags=sw._lib.FLAG_ROLLOUT_QUAD)
+    traj = torch.empty((H - 1, 8, R), dtype=torch.float64, device="cuda:0")
+    ret = sw.kernels.rollout(p, H - 1, pol, traj=traj)
+    lane = sw.kernels.rollout(sw.SwParams.make(n, flags=sw._lib.FLAG_ROLLOUT_LANE), H - 1, pol)
+    assert np.abs((ret - lane).cpu().numpy()).max() <= 1e-9 and not torch.equal(ret, lane)
+    assert np.abs(traj[1000, :, ::97].cpu().numpy() - out["lane"][2]).max() <= 1e-10
 
 
 def _traj_keys(t):
@@ -363,20 +436,23 @@ def test_pipeline_follows_the_callers_stream(sw):
     assert np.allclose(cov, np.cov(states.T), rtol=1e-9, atol=1e-12)
 
 
-def test_top_b_variant_matches_safe_ars_semantics(sw):
-    """safe_ars/ars.py:48-65, :95-96: only the best b directions enter sigma_R and the step."""
-    from oracle.ars_oracle import ArsOracle
-    N, b, H = 8, 3, 80
-    ep = sw.EnvParam("LeonSwimmer-Test", n=3, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
-    ap = sw.ARSParam("Test", V1=True, n_iter=3, H=H, N=N, b=b, alpha=0.01, nu=0.02, safe=False,
+@pytest.mark.parametrize("tag", ["basic_n3_N8_b3", "basic_n3_N4_b6", "basic_n6_N4_b2"])
+def test_top_b_variant_vs_reference_basic_ars(sw, golden, tag):
+    """safe_ars/ars.py Basic_ARS.train (:67-98) as the REFERENCE ran it (tests/golden/next_rows.npz):
+    only the best b directions enter sigma_R and the step (:57-63, :96) and the divisor is
+    len(order) (:64).  basic_n3_N4_b6 has b = 6 > N = 4, where dividing by b would be wrong."""
+    g = golden.next_rows
+    n, N, b, H, seed, iters = (int(v) for v in g[tag + "_cfg"])
+    l, m, k, h, alpha, nu = (float(v) for v in g[tag + "_phys"])
+    ep = sw.EnvParam("LeonSwimmer-Test", n=n, H=H, l_i=l, m_i=m, h=h, k=k, epsilon=0)
+    ap = sw.ARSParam("Test", V1=True, n_iter=iters, H=H, N=N, b=b, alpha=alpha, nu=nu, safe=False,
                      threshold=0, initial_w="Zero")
-    agent = sw.ARSAgent(ep, ap, seed=4, top_b=b)
-    o = ArsOracle(3, 1.0, 1.0, 10.0, 1e-3, H, N, b, 0.01, 0.02, True, 4, top_b=b)
-    for it in range(3):
+    agent = sw.ARSAgent(ep, ap, seed=seed, top_b=b)
+    for it in range(iters):
         r = np.array(agent.runOneIteration())
-        ro = np.array(o.iteration())
-        assert np.abs(r - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
-        assert np.abs(agent.policy - o.policy).max() <= 1e-9
+        ref = g[tag + "_returns"][it]
+        assert np.abs(r - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+        assert np.abs(agent.policy - g[tag + "_policies"][it]).max() <= 1e-9
 
 
 def test_checkpoint_resume_is_bit_exact(sw, tmp_path):
@@ -422,37 +498,60 @@ def test_vec_env_matches_oracle_over_steps(sw):
     assert len(env._plans) == 2     # two pre-bound launches (A->B, B->A), reused
 
 
-def test_estimator_objective_is_one_batched_step(sw):
-    """ars/estimator.py:36-62: I(x) over stored transitions, here one step-kernel launch."""
+def test_round1_checkpoint_files_still_load(sw, tmp_path):
+    """A format-1 checkpoint (round 1: no `format` key, running = raw sums {n, S1, S2} about the
+    reset pivot, cov_acc = total sums) is converted on load: {n, S1 / n, S2 - S1^2 / n}.  Built here
+    from a format-2 file of the same agent by the inverse map; the continuation must agree with
+    the original run to rounding (the conversion is not bit-exact, the format-2 path is)."""
+    ep = sw.EnvParam("LeonSwimmer-Test", n=3, H=120, l_i=0.8, m_i=1.2, h=1e-3, k=10.2, epsilon=0)
+    ap = sw.ARSParam("Test", V1=False, n_iter=4, H=120, N=6, b=6, alpha=0.0075, nu=0.01,
+                     safe=False, threshold=0, initial_w="Zero")
+    a = sw.ARSAgent(ep, ap, seed=21, full_covariance=True)
+    for _ in range(3):
+        a.runOneIteration()
+    a.save_checkpoint(str(tmp_path / "f2.npz"))
+    z = dict(np.load(str(tmp_path / "f2.npz"), allow_pickle=False))
+    assert int(z.pop("format")) == 2
+    n, mc, m2 = z["running"][0], z["running"][1:9], z["running"][9:]
+    s1 = n * mc
+    z["running"] = np.concatenate(([n], s1, m2 + s1 * s1 / n))
+    np.savez(str(tmp_path / "f1.npz"), **z)
+    tail_a = [a.runOneIteration() for _ in range(2)]
+    b = sw.ARSAgent(ep, ap, seed=777, full_covariance=True)
+    b.load_checkpoint(str(tmp_path / "f1.npz"))
+    assert b.n_saved_states == 3 * 2 * 6 * 120
+    tail_b = [b.runOneIteration() for _ in range(2)]
+    assert np.abs(np.array(tail_a) - np.array(tail_b)).max() <= 1e-9 * max(1.0, np.abs(np.array(tail_a)).max())
+    assert np.abs(a.policy - b.policy).max() <= 1e-9
+    assert np.allclose(a.mean, b.mean, rtol=0, atol=1e-13)
+    sd = np.sqrt(np.diag(a.covariance))
+    assert (np.abs(a.covariance - b.covariance) <= 1e-9 * np.outer(sd, sd)).all()   # cov_acc was restored
+
+
+def test_estimator_objectives_vs_reference(sw, golden):
+    """ars/estimator.py:36-87: I(x) over stored transitions (here ONE step-kernel launch) and J(x)
+    (one rollout launch per stored rollout) against the values the REFERENCE's Estimator returned
+    for a Database of its own rollouts (tests/golden/next_rows.npz), same subset draw."""
     from swimmer_amd.ars.estimator import Estimator
     from swimmer_amd.ars.database import Database
-    H = 60
-    true = sw.EnvParam("real", n=3, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
-    rng = np.random.RandomState(2)
+    g = golden.next_rows
+    H = g["est_trajectories"].shape[1]
     db = Database()
-    op = oracle.OracleParams.make(3, 1.0, 1.0, 10.0, 1e-3)
-    for _ in range(3):
-        P = 0.2 * (2 * rng.rand(2, 8) - 1)
-        _, traj = oracle.rollout(op, H, P, state0=np.r_[0.1, -0.2, rng.uniform(-2, 2, 6)])
-        db.add_trajectory(traj.tolist(), P)
-    np.random.seed(0)
-    est = Estimator(db, sw.EnvParam("guess", n=3, H=H, l_i=1.01, m_i=1.01, h=1e-3, k=10.01,
-                                    epsilon=0.01), capacity=2)
-    assert est.I([1.0, 1.0, 10.0]) < 1e-11          # the reference asserts 0.0 at the true params
-    def ref_I(x):
-        q = oracle.OracleParams.make(3, x[1], x[0], x[2], 1e-3)   # unknowns = (m_i, l_i, k)
-        tot = 0.0
-        for k in est.subset:
-            tr, P = np.array(db.trajectories[k]), db.policies[k]
-            for t in range(H - 1):
-                nxt, _ = oracle.step(q, tr[t], P @ tr[t])
-                tot += np.linalg.norm(nxt - tr[t + 1])
-        return tot
-    for x in ([1.01, 1.01, 10.01], [0.9, 1.2, 9.0]):
-        assert est.I(x) == pytest.approx(ref_I(x), rel=1e-9)
+    for P, tr in zip(g["est_policies"], g["est_trajectories"]):
+        db.add_trajectory(tr.tolist(), P)
+    m_i, l_i, k, h = (float(v) for v in g["est_guess"])
+    guess = sw.EnvParam("Simulator with estimation", n=3, H=H, l_i=l_i, m_i=m_i, h=h, k=k, epsilon=0.01)
+    np.random.seed(12)
+    est = Estimator(db, guess, capacity=len(g["est_subset"]))
+    assert np.array_equal(est.subset, g["est_subset"])          # estimator.py:33, same stream
+    for x, want_I, want_J in zip(g["est_x"], g["est_I"], g["est_J"]):
+        if want_I == 0.0:     # the true parameters: the reference asserts exactly 0.0 (:138)
+            assert est.I(x) < 1e-11 and est.J(x) < 1e-13
+        else:
+            assert est.I(x) == pytest.approx(want_I, rel=1e-9)
+            assert est.J(x) == pytest.approx(want_J, rel=1e-9)
     assert est.convert_to_env_param([1.5, 0.5, 7.0]) == sw.EnvParam(
-        "guess", n=3, H=H, l_i=0.5, m_i=1.5, h=1e-3, k=7.0, epsilon=0.01)
-    assert est.J([1.0, 1.0, 10.0]) > 1e-3   # rollouts from reset differ from the stored ones
+        "Simulator with estimation", n=3, H=H, l_i=0.5, m_i=1.5, h=h, k=7.0, epsilon=0.01)
 
 
 def test_large_batch_properties(sw):

@@ -69,3 +69,30 @@ def test_exchange_single_rank_is_identity():
     assert ra is r and ma is m
     buf = pack_local(r[:6], m, 4, 2)
     assert buf.numel() == 8 + 2 * 16 and float(buf[6]) == 0.0 and float(buf[8]) == 1.0
+
+
+def test_database_refuses_mixed_or_incomplete_shard_sets(tmp_path):
+    """Database.load(path) falls back to the per-rank shards of a distributed run; left-overs of
+    a run with another world size, or a missing rank, must raise instead of merging silently."""
+    stem = str(tmp_path / "store")
+    P, T = np.zeros((2, 8)), np.zeros((5, 8))
+
+    def shard(rank, world, n):
+        db = Database()
+        for i in range(n):
+            db.add_trajectory((T + 10 * rank + i).tolist(), P + rank)
+        db.save(stem + ".npz", rank=rank, world=world)
+
+    shard(0, 2, 2)
+    shard(1, 2, 3)
+    db = Database()
+    db.load(stem + ".npz")
+    assert db.size == 5 and db.policies[2][0, 0] == 1.0          # rank order: 0, 0, 1, 1, 1
+    shard(0, 4, 1)                                               # left-over of another run
+    with pytest.raises(ValueError, match="several runs"):
+        Database().load(stem + ".npz")
+    db = Database()
+    db.load(stem + ".npz", world=2)                              # explicit choice is honoured
+    assert db.size == 5
+    with pytest.raises(ValueError, match="incomplete"):
+        Database().load(stem + ".npz", world=4)                  # ranks 1..3 of world 4 missing

@@ -109,7 +109,9 @@ def test_update_beyond_the_lds_capacity(sw, top_b):
         order = np.arange(N)
     used = r[order].reshape(-1)
     sigma = np.std(used)
-    grad = ((r[order, 0] - r[order, 1])[:, None, None] * deltas[order]).sum(0) / (b * sigma)
+    # divisor: b when every direction is used (ars_agent.py:128), len(order) with a true top-b
+    # truncation (safe_ars/ars.py:64)
+    grad = ((r[order, 0] - r[order, 1])[:, None, None] * deltas[order]).sum(0) / ((top_b or b) * sigma)
     want = P0 + alpha * grad
     assert abs(sig.item() - sigma) <= 1e-13 * sigma
     assert np.abs(pol.cpu().numpy() - want).max() <= 1e-11 * np.abs(want).max()

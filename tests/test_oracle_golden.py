@@ -160,3 +160,46 @@ def test_oracle_vs_both_states_of_coulom_program():
         assert gy < 1e-5             # recorded -8e-11; 1.5708 is not exactly pi / 2
         assert res < 1e-5            # the recorded angle accelerations are consistent (3 eq., 2 unknowns)
         assert np.abs(u - u[0]).max() < 1e-3 and 0.0 < u[0] < 0.1   # a small symmetric torque
+
+
+# ---- round 3: the "next" rows pinned to the reference itself (tests/golden/next_rows.npz) ----
+BASIC_CASES = ("basic_n3_N8_b3", "basic_n3_N4_b6", "basic_n6_N4_b2")
+
+
+@pytest.mark.parametrize("tag", BASIC_CASES)
+def test_basic_ars_top_b_vs_reference(golden, tag):
+    """safe_ars/ars.py Basic_ARS.train (:67-98) as the reference ran it: only order[:b] enters
+    sigma_R and the step (:57-63, :96) and the divisor is len(order) (:64) -- NOT b (case
+    basic_n3_N4_b6 has b = 6 > N = 4: len(order) = 4).  The oracle's top-b branch against it."""
+    g = golden.next_rows
+    n, N, b, H, seed, iters = (int(v) for v in g[tag + "_cfg"])
+    l, m, k, h, alpha, nu = g[tag + "_phys"]
+    o = ArsOracle(n, l, m, k, h, H, N, b, alpha, nu, True, seed, top_b=b)
+    for it in range(iters):
+        r = np.array(o.iteration())
+        ref = g[tag + "_returns"][it]
+        assert np.abs(r - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+        assert np.mean(r) == pytest.approx(g[tag + "_curve"][it], rel=1e-9, abs=1e-15)
+        assert np.abs(o.policy - g[tag + "_policies"][it]).max() <= 1e-9
+    # the divisor matters: with b in its place the b > N case lands elsewhere
+    if b > N:
+        wrong = ArsOracle(n, l, m, k, h, H, N, b, alpha, nu, True, seed, top_b=0)
+        wrong.iteration()
+        assert np.abs(wrong.policy - g[tag + "_policies"][0]).max() > 1e-6
+
+
+def test_estimator_objectives_vs_reference(golden):
+    """ars/estimator.py:36-87 as the reference evaluated them on a Database of three of its own
+    rollouts with the subset its constructor drew (capacity 4 of 3: one rollout counts twice)."""
+    from oracle.estimator_oracle import objective_I, objective_J
+    g = golden.next_rows
+    guess = dict(zip(("m_i", "l_i", "k", "h"), g["est_guess"]))
+    args = (g["est_policies"], g["est_trajectories"], g["est_subset"])
+    assert len(set(g["est_subset"].tolist())) < len(g["est_subset"])
+    for x, want_I, want_J in zip(g["est_x"], g["est_I"], g["est_J"]):
+        got_I, got_J = objective_I(3, guess, x, *args), objective_J(3, guess, x, *args)
+        if want_I == 0.0:            # true parameters: the reference asserts exactly 0.0 (:138)
+            assert got_I < 1e-12 and got_J < 1e-14
+        else:
+            assert got_I == pytest.approx(want_I, rel=1e-11)
+            assert got_J == pytest.approx(want_J, rel=1e-11)
