@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--collective-one-rank-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--direct-rccl", action="store_true",
+                    help="issue the all-gather straight into RCCL from native code (sw_comm) "
+                         "instead of through torch.distributed")
     return ap.parse_args(argv)
 
 
@@ -492,12 +495,12 @@ def aux_rollout_saturated(sw, torch, device, n=3, n_roll=262144, H=1000, reps=3)
 class ArsLeg(object):
     """One ARS V2 workload on this rank: agent + the timed loop + the kernel-timing post-pass."""
 
-    def __init__(self, sw, torch, n, H, N, device):
+    def __init__(self, sw, torch, n, H, N, device, direct_rccl=None):
         self.sw, self.torch, self.n, self.H, self.N = sw, torch, n, H, N
         ep = sw.EnvParam("LeonSwimmer-Bench", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
         ap = sw.ARSParam("Bench", V1=False, n_iter=0, H=H, N=N, b=N, alpha=0.0075, nu=0.01,
                          safe=False, threshold=0, initial_w="Zero")
-        self.agent = sw.ARSAgent(ep, ap, seed=0, device=device, full_covariance=True)
+        self.agent = sw.ARSAgent(ep, ap, seed=0, device=device, full_covariance=True, direct_rccl=direct_rccl)
 
     def run(self, warmup, steps, sync, time_every=TIME_EVERY, postpass=POSTPASS_LAUNCHES):
         agent, torch = self.agent, self.torch
@@ -549,7 +552,7 @@ def leg_roofline(n, n_local, H, kern_ms):
             "issue_bound": issue_bound(n, H, kern_ms)}
 
 
-def aux_collective_one_rank(n, H, directions, timeout=150):
+def aux_collective_one_rank(n, H, directions, timeout=150, direct=False):
     """What the per-iteration all-gather costs BEFORE any wire time: the same ARS loop with a
     one-rank RCCL process group and the collective forced (ProcessGroupNCCL + the RCCL kernel on
     the critical stream).  The multi-GPU iteration is this plus the time on the xGMI links.
@@ -557,6 +560,8 @@ def aux_collective_one_rank(n, H, directions, timeout=150):
     some box must not take the N = 1 line with it."""
     cmd = [sys.executable, os.path.abspath(__file__), "--collective-one-rank-child",
            "--segments", str(n), "--horizon", str(H), "--directions", str(directions)]
+    if direct:      # the same loop with ncclAllGather called from native code (sw_comm_all_gather_f64)
+        cmd.append("--direct-rccl")
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
@@ -585,11 +590,15 @@ def collective_one_rank_child(args):
         torch.cuda.set_stream(torch.cuda.Stream(device))
         sharding._FORCE_COLLECTIVE = True
         iters = 20
-        leg = ArsLeg(sw, torch, args.segments, args.horizon, args.directions, device)
+        leg = ArsLeg(sw, torch, args.segments, args.horizon, args.directions, device,
+                     direct_rccl=args.direct_rccl)
         r = leg.run(3, iters, torch.cuda.synchronize, time_every=4, postpass=16)
         leg.check(0)
+        import hashlib
         res = {"directions": args.directions, "ms_per_iteration": r["seconds"] / iters * 1e3,
                "collective_us": r.get("collective_us"), "backend": dist.get_backend(),
+               "path": "sw_comm_all_gather_f64 (native)" if args.direct_rccl else "torch.distributed",
+               "policy_sha256": hashlib.sha256(leg.agent.policy.tobytes()).hexdigest()[:16],
                "note": "one rank, all-gather forced: framework + RCCL launch cost per iteration, no wire time"}
         dist.destroy_process_group()
     print(json.dumps(res), flush=True)
@@ -723,7 +732,7 @@ def run_rank(args):
     N = args.directions * world if args.scaling == "weak" else args.total_directions
     if rank == 0:
         calibrate_issue_intervals(sw, device)
-    leg = ArsLeg(sw, torch, n, H, N, device)
+    leg = ArsLeg(sw, torch, n, H, N, device, direct_rccl=(True if args.direct_rccl else None))
     agent = leg.agent
     res = leg.run(args.warmup, args.steps, sync)
     dt = max_over_ranks(res["seconds"])
@@ -830,6 +839,7 @@ def run_rank(args):
             aux["shard_n3_256_directions"] = guarded(aux_ars_shard, sw, torch, 3, H, 256, device)
             aux["shard_n6_256_directions"] = guarded(aux_ars_shard, sw, torch, 6, H, 256, device)
             aux["collective_one_rank"] = guarded(aux_collective_one_rank, n, H, args.directions)
+            aux["collective_one_rank_direct"] = guarded(aux_collective_one_rank, n, H, args.directions, direct=True)
             aux["next_rows"] = guarded(aux_next_rows, sw, torch, device)
             aux["rollout_saturated"] = guarded(aux_rollout_saturated, sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster

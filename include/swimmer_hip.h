@@ -217,6 +217,25 @@ int sw_env1_step(sw_env1 *e, const sw_params *p, int32_t *status);
 /* compute_accelerations of the state / action in the block (remy_swimmer_env.py:95-114). */
 int sw_env1_accel(sw_env1 *e, const sw_params *p);
 
+/* ---- the exchange step of the sharded ARS iteration, straight into RCCL -----------------
+ * One all-gather of every rank's packed result segment per iteration replaces the serial loop
+ * over directions (ars/ars_agent.py:160 "TODO ... PARALLEL"); see sw_ars_update_gathered_f64 for
+ * the layout.  These entry points issue it from native code ON THE CALLER'S STREAM (the critical
+ * stream rollouts -> all-gather -> update), without torch.distributed in between.  RCCL is
+ * resolved at run time (dlopen by soname: the copy a torch process has loaded already), so the
+ * library has no link-time dependency on it; sw_comm_available() says whether it was found.
+ * Rank 0 draws the id, the caller distributes its SW_COMM_ID_BYTES bytes by whatever means it has
+ * (torch.distributed broadcast, MPI, a file), every rank creates its communicator (collective). */
+#define SW_COMM_ID_BYTES 128
+typedef struct sw_comm sw_comm;
+int sw_comm_available(void);
+int sw_comm_unique_id(uint8_t *id /* host, SW_COMM_ID_BYTES */);
+int sw_comm_create(sw_comm **out, const uint8_t *id, int32_t world, int32_t rank);
+void sw_comm_destroy(sw_comm *c);
+/* recv[r * count .. (r+1) * count) <- rank r's send[0 .. count)  (device pointers). */
+int sw_comm_all_gather_f64(sw_comm *c, const double *send, double *recv, int64_t count, void *stream);
+const char *sw_comm_last_error(sw_comm *c);
+
 /* ---- measurement aid ---------------------------------------------------------------------
  * One wave issuing trips x 64 independent instructions of one class (mode 0: v_fma_f64,
  * mode 1: v_mov_b32); scratch64: 64 doubles.  bench.py times it with HIP events to calibrate the

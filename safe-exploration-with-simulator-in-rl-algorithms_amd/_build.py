@@ -6,10 +6,11 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SWIMMER_HIP_LIB") or os.path.join(CSRC, "libswimmer_hip.so")  # override: experiments
-SOURCES = ["swimmer_kernels.hip", "host_rng.cpp"]
+SOURCES = ["swimmer_kernels.hip", "host_rng.cpp", "direct_comm.cpp"]
 HEADERS = ["rlglue_env.cpp", os.path.join("..", "..", "include", "rlglue_swimmer.h"),
            "swimmer_device.h", "swimmer_quad3.h", "swimmer_row.h", "swimmer_row_fused.h", "swimmer_twin.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+LINK_LIBS = ["-ldl"]   # direct_comm.cpp resolves RCCL at run time
 
 
 def _hipcc():
@@ -35,7 +36,7 @@ def build_library(force=False, verbose=False):
     RL-Glue environment plug-in (csrc/librlglue_swimmer_hip.so) on top of it."""
     if not force and not is_stale() and os.path.exists(RLGLUE_LIB_PATH):
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + LINK_LIBS + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

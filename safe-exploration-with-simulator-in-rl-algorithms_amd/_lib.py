@@ -88,6 +88,14 @@ _PROTOTYPES = {
     "sw_env1_io": (ctypes.POINTER(ctypes.c_double), [ctypes.c_void_p]),
     "sw_env1_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "sw_env1_accel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "sw_comm_available": (ctypes.c_int, []),
+    "sw_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "sw_comm_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int32,
+                                      ctypes.c_int32]),
+    "sw_comm_destroy": (None, [ctypes.c_void_p]),
+    "sw_comm_all_gather_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_int64, ctypes.c_void_p]),
+    "sw_comm_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "sw_issue_probe": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "sw_mt19937_uniform_pm1": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
                                               ctypes.c_int64, ctypes.c_void_p]),

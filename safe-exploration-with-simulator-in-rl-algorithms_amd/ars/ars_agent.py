@@ -46,7 +46,7 @@ class ARSAgent(object):
     def __init__(self, real_env_param, agent_param, data_path=None, seed=None,
                  guess_param=None, approx_error=None, sim_thresh=None, *, device=None,
                  process_group=None, record_trajectories=False, full_covariance=True,
-                 top_b=0, rollout_kernel="auto"):
+                 top_b=0, rollout_kernel="auto", direct_rccl=None):
         if agent_param.safe:
             raise NotImplementedError(
                 "safe exploration (ars_agent.py:144-157) gates every real rollout on a "
@@ -135,9 +135,37 @@ class ARSAgent(object):
         self._status = torch.zeros(max(1, 2 * self.n_local), dtype=torch.int32,
                                    device=self.device)
 
+        # The exchange: torch.distributed (default), or -- direct_rccl=True / SWIMMER_DIRECT_RCCL=1 --
+        # ncclAllGather called from native code on the critical stream with a communicator of this
+        # agent's own (sw_comm, include/swimmer_hip.h).  Same bytes either way; torch stays the
+        # default until the direct path has met more than one rank.
+        if direct_rccl is None:
+            direct_rccl = os.environ.get("SWIMMER_DIRECT_RCCL", "0") not in ("", "0")
+        self._comm = None
+        if direct_rccl and (self.world > 1 or _sh._FORCE_COLLECTIVE):
+            if self.world > 1 and dist.get_backend(self.group) != "nccl":
+                raise SwimmerHipError("direct_rccl needs GPU ranks (backend nccl), one per device")
+            self._comm = kernels.DirectComm(self.world, self.rank, self._broadcast_bytes)
+
         # Randomness: the reference seeds NumPy's global generator (ars_agent.py:94-95)
         self.n_seed = seed
         np.random.seed(self.n_seed)
+
+    def _broadcast_bytes(self, payload):
+        """Rank 0's 128 id bytes to every rank of the group (COLLECTIVE)."""
+        if self.world == 1:
+            return payload
+        t = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(t, src=src, group=self.group)
+        return bytes(t.cpu().numpy().tobytes())
+
+    def _exchange(self):
+        if self._comm is not None:
+            return self._comm.all_gather(self._send, self._gathered)
+        return all_gather_segments(self._send, self._gathered, self.world, self.group)
 
     # ---- attributes the reference exposes -------------------------------------------
     @property
@@ -261,11 +289,11 @@ class ARSAgent(object):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            gathered = all_gather_segments(self._send, self._gathered, self.world, self.group)
+            gathered = self._exchange()
             e1.record()
             self._coll_events.append((e0, e1))
         else:
-            gathered = all_gather_segments(self._send, self._gathered, self.world, self.group)
+            gathered = self._exchange()
         n_new = 2 * ap.N * ap.H
         self._pipe.update(i, self.params, ap.N, gathered, self.world, self.chunk,
                           self.rows_chunk, self._deltas, self._policy, ap.alpha, ap.b,

@@ -68,6 +68,41 @@ class StepPlan(object):
             check(rc, "sw_step_f64")
 
 
+class DirectComm(object):
+    """sw_comm: the per-iteration all-gather issued straight into RCCL from native code on the
+    current stream (no ProcessGroupNCCL in between).  COLLECTIVE constructor: rank 0 draws the
+    unique id, `broadcast_id(id_bytes_or_None)` must hand every rank rank 0's 128 bytes."""
+
+    def __init__(self, world, rank, broadcast_id):
+        require_gpu()
+        lib = load()
+        if not lib.sw_comm_available():
+            raise _lib.SwimmerHipError("RCCL (librccl.so.1) could not be resolved at run time")
+        buf = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            check(lib.sw_comm_unique_id(buf), "sw_comm_unique_id")
+        ident = broadcast_id(bytes(buf) if rank == 0 else None)
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(ident)
+        h = ctypes.c_void_p()
+        check(lib.sw_comm_create(ctypes.byref(h), buf, world, rank), "sw_comm_create")
+        self._h, self._lib, self.world, self.rank = h, lib, world, rank
+        self._fn = lib.sw_comm_all_gather_f64
+
+    def all_gather(self, send, gathered):
+        """gathered[r * L : (r + 1) * L] <- rank r's send (L = send.numel()), on the current stream."""
+        if gathered.numel() != self.world * send.numel():
+            raise _lib.SwimmerHipError("all_gather: gathered must hold world x send doubles")
+        rc = self._fn(self._h, ptr(send), ptr(gathered), send.numel(), stream_ptr())
+        if rc:
+            raise _lib.SwimmerHipError("sw_comm_all_gather_f64: " + self._lib.sw_comm_last_error(self._h).decode())
+        return gathered
+
+    def close(self):
+        if self._h is not None:
+            self._lib.sw_comm_destroy(self._h)
+            self._h = None
+
+
 class SingleEnv(object):
     """sw_env1: ONE swimmer handed over in host memory -- the batch-1 surface under
     `SwimmerEnv.step` (remy_swimmer_env.py:41-56).  The handle owns a pinned, device-mapped I/O

@@ -27,7 +27,7 @@ def test_plain_c_client(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = dict((l.split()[0], l.split()[1:]) for l in out.stdout.strip().splitlines())
-    assert lines["abi"] == ["2", "max_segments", "8"]
+    assert lines["abi"] == ["3", "max_segments", "8"]
     p = oracle.OracleParams.make(3, 0.8, 1.2, 10.2, 1e-3)
     state = np.array([0.1, -0.2, 1.0, 0.5, 2.0, -0.3, -1.0, 0.25])
     nxt, rew = oracle.step(p, state, [1.5, -2.5])
