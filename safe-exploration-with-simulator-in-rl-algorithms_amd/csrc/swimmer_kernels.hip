@@ -470,16 +470,22 @@ struct CovTiling {
     int32_t tchunk;
 };
 
-CovTiling cov_tiling(int64_t n_roll, int32_t H, int block)
+// Long chains (D >= 14, n >= 6) in 256-thread workgroups: the D (D + 1) / 2 + D sums do not fit one
+// lane's registers, so the four waves of the workgroup work on the SAME 64 rollouts and split the
+// sums between them (moments_split): a tile is 64 rollouts wide and four times as long.
+__host__ __device__ constexpr bool cov_split(int D, int block) { return D >= 14 && block >= 256; }
+
+CovTiling cov_tiling(int64_t n_roll, int32_t H, int block, int D)
 {
     CovTiling t;
-    t.nbx = (uint32_t)((n_roll + block - 1) / block);
+    const int cols = cov_split(D, block) ? kWave : block;   // rollouts per tile
+    t.nbx = (uint32_t)((n_roll + cols - 1) / cols);
     // steps per tile: long tiles for the one-wave workgroups of the quad kernel's launches -- a tile
     // ends with a cross-lane reduction of all its accumulators, and once a batch puts a wave on
     // every SIMD those epilogues are the rollouts' time (2048 directions on one GPU, n = 3: launch
     // 0.2798 ms with 64 steps per tile, 0.2663 with 128, 0.384 with 32; no difference at 512
     // directions; profiles/r02_f_cov_tile_sweep.log)
-    int32_t base = (block >= kMomBlock) ? kMomTChunk : 128;
+    int32_t base = (block >= kMomBlock) ? (cov_split(D, block) ? 4 * kMomTChunk : kMomTChunk) : 128;
     static const char *env = getenv("SWIMMER_COV_TCHUNK");   // measurement knob
     if (env && atoi(env) > 0) base = atoi(env);
     const uint32_t ny_max = (uint32_t)((H + base - 1) / base);
@@ -573,6 +579,93 @@ struct MomentsPasses {
     }
 };
 
+// ---- long chains: the sums of a tile split over the four waves of the workgroup -----------------
+// items 0 .. D-1 are the first moments, item D + p is pair p = (f, g), f <= g, of the upper triangle
+// in row-major order.  Wave w owns items [w * PER, (w + 1) * PER): ~30 accumulators for D = 14
+// instead of 119, so ONE pass over the tile suffices (the multi-pass form re-reads it 2-4 times),
+// two steps' loads are in flight at a time, and the waves' loads of the same 64 rollouts hit in the
+// vector L1 / L2 after the first one.  Each wave reduces its own sums over the lanes and writes them
+// to the tile's row: no LDS, no barrier.
+__host__ __device__ constexpr int pair_row(int D, int p)
+{
+    int f = 0;
+    while (p >= D - f) {
+        p -= D - f;
+        ++f;
+    }
+    return f;
+}
+__host__ __device__ constexpr int pair_col(int D, int p)
+{
+    int f = 0;
+    while (p >= D - f) {
+        p -= D - f;
+        ++f;
+    }
+    return f + p;
+}
+
+template <int D, int WV>
+__device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double *__restrict__ traj,
+                                                   double *__restrict__ tile_row, int64_t bx, int32_t t0,
+                                                   int32_t t1)
+{
+    constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4;
+    constexpr int Q0 = WV * PER, Q1 = (Q0 + PER < ITEMS) ? Q0 + PER : ITEMS;
+    const int l = threadIdx.x % kWave;
+    const int64_t r = bx * kWave + l;
+    double acc[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) acc[q] = 0.0;
+    auto load = [&](double (&x)[D], int32_t t) {
+        const double *tp = traj + (int64_t)t * D * n_roll + r;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {   // columns this wave never multiplies are dropped by the compiler
+            const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
+            x[j] = tp[(int64_t)j * n_roll] - c;
+        }
+    };
+    auto add = [&](const double (&x)[D]) {
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) {
+            if (q < D) acc[q - Q0] += x[q];
+            else acc[q - Q0] = __builtin_fma(x[pair_row(D, q - D)], x[pair_col(D, q - D)], acc[q - Q0]);
+        }
+    };
+    if (r < n_roll && t0 < t1) {
+        double xa[D], xb[D];
+        load(xa, t0);
+        for (int32_t t = t0; t < t1; t += 2) {
+            if (t + 1 < t1) load(xb, t + 1);
+            add(xa);
+            if (t + 2 < t1) load(xa, t + 2);
+            if (t + 1 < t1) add(xb);
+        }
+    }
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+        double v = acc[q - Q0];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+        if (l == 0) {
+            if (q < D) tile_row[q] = v;
+            else tile_row[D + pair_row(D, q - D) * D + pair_col(D, q - D)] = v;   // upper triangle only
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void moments_split(int64_t n_roll, const double *__restrict__ traj,
+                                              double *__restrict__ tile_row, int64_t bx, int32_t t0, int32_t t1)
+{
+    switch (threadIdx.x / kWave) {   // wave-uniform
+    case 0: moments_split_wave<D, 0>(n_roll, traj, tile_row, bx, t0, t1); break;
+    case 1: moments_split_wave<D, 1>(n_roll, traj, tile_row, bx, t0, t1); break;
+    case 2: moments_split_wave<D, 2>(n_roll, traj, tile_row, bx, t0, t1); break;
+    default: moments_split_wave<D, 3>(n_roll, traj, tile_row, bx, t0, t1); break;
+    }
+}
+
 // Tile `tile` of `n_tiles` (tile = by * nbx + bx).  acc = [sums | counter | n_tiles rows].
 template <int D, int BLOCK>
 __device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const double *__restrict__ traj,
@@ -583,10 +676,15 @@ __device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const do
     // plus one state inside 256 VGPRs -- one pass up to D = 12, 2 / 3 / 4 passes for D = 14 / 16 / 18
     constexpr int JB = (D <= 12) ? D : (D == 14 ? 7 : (D == 16 ? 6 : 5));
     constexpr int W = D + D * D;
-    __shared__ double sh[(BLOCK / kWave) * (D + JB * D)];
     __shared__ uint32_t ticket;
     double *rows = acc + cov_sums(D) + 1;
-    MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1, sh);
+    if constexpr (cov_split(D, BLOCK)) {
+        static_assert(BLOCK == 4 * kWave, "moments_split: four waves per workgroup");
+        moments_split<D>(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1);
+    } else {
+        __shared__ double sh[(BLOCK / kWave) * (D + JB * D)];
+        MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1, sh);
+    }
     __threadfence();   // this tile's row is visible device-wide before its ticket is
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1458,14 +1556,14 @@ const SideJob kNoSide{nullptr, 0u, UINT32_MAX, 1u, 0u, 0, 0, 0, nullptr, nullptr
 
 // Attach a covariance pass over (cov_traj, cov_rolls, cov_H) to a launch of `roll_blocks` rollout
 // workgroups of `block` threads; returns the number of extra workgroups.
-unsigned side_attach_cov(SideJob &sj, unsigned roll_blocks, int block)
+unsigned side_attach_cov(SideJob &sj, unsigned roll_blocks, int block, int sj_D)
 {
     sj.first_cov_block = roll_blocks;
     if (!sj.cov_traj || sj.cov_rolls <= 0 || sj.cov_H <= 0) {
         sj.first_cov_block = UINT32_MAX;
         return 0;
     }
-    const CovTiling t = cov_tiling(sj.cov_rolls, sj.cov_H, block);
+    const CovTiling t = cov_tiling(sj.cov_rolls, sj.cov_H, block, sj_D);
     sj.cov_nbx = t.nbx;
     sj.cov_tchunk = t.tchunk;
     sj.cov_tiles = t.nbx * t.ny;
@@ -1638,7 +1736,7 @@ static int launch_ars_rollouts(const sw_params *p, int64_t dir_begin, int64_t n_
     if (use_quad3(p, n_roll, H, traj != nullptr)) {
         unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
         SideJob sj = side ? *side : kNoSide;
-        grid += side_attach_cov(sj, grid, kRollBlock);
+        grid += side_attach_cov(sj, grid, kRollBlock, 2 * p->n + 2);
         if (side_taken) *side_taken = side != nullptr;
         SW_DISPATCH_QUAD(true, traj != nullptr, moments != nullptr,
                          (hipStream_t)stream, C, n_roll, H, policy, deltas, dir_begin, nu, mean,
@@ -1649,7 +1747,7 @@ static int launch_ars_rollouts(const sw_params *p, int64_t dir_begin, int64_t n_
     if (use_row(p, n_roll, H, traj != nullptr)) {
         unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
         SideJob sj = side ? *side : kNoSide;
-        grid += side_attach_cov(sj, grid, kRowBlock);
+        grid += side_attach_cov(sj, grid, kRowBlock, 2 * p->n + 2);
         if (side_taken) *side_taken = side != nullptr;
         SW_DISPATCH_ROW(p->n, true, traj != nullptr, moments != nullptr, (hipStream_t)stream, C,
                         n_roll, H, policy, deltas, dir_begin, nu, mean, inv_std,
@@ -1746,7 +1844,7 @@ static int launch_traj_moments(const sw_params *p, int64_t n_roll, int32_t H, co
     if (n_roll < 0 || H < 0) return SW_ERR_SIZE;
     if (n_roll == 0 || H == 0) return SW_OK;
     if (!traj || !acc) return SW_ERR_NULL;
-    const CovTiling t = cov_tiling(n_roll, H, block);
+    const CovTiling t = cov_tiling(n_roll, H, block, 2 * p->n + 2);
     const dim3 grid(t.nbx * t.ny);
     if (block == kRollBlock) {
         SW_DISPATCH_N(p->n, hipLaunchKernelGGL((traj_moments_kernel<2 * NN + 2, kRollBlock>), grid,
@@ -1766,7 +1864,7 @@ int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H)
     const int d = 2 * p->n + 2;
     int64_t tiles = 0;
     if (n_roll > 0 && H > 0) {
-        const CovTiling a = cov_tiling(n_roll, H, kRollBlock), b = cov_tiling(n_roll, H, kMomBlock);
+        const CovTiling a = cov_tiling(n_roll, H, kRollBlock, d), b = cov_tiling(n_roll, H, kMomBlock, d);
         const int64_t ta = (int64_t)a.nbx * a.ny, tb = (int64_t)b.nbx * b.ny;
         tiles = ta > tb ? ta : tb;
     }
@@ -1799,6 +1897,7 @@ int sw_env1_create(sw_env1 **out)
         memset(e->io_host, 0, bytes);
         ok = hipHostGetDevicePointer((void **)&e->io_dev, e->io_host, 0) == hipSuccess &&
              hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+        // (normal priority: a batch-1 step has nothing to overtake)
     }
     if (!ok) {
         sw_env1_destroy(e);
@@ -1942,7 +2041,15 @@ int sw_ars_pipeline_create(sw_ars_pipeline **out)
     sw_ars_pipeline *pl = new (std::nothrow) sw_ars_pipeline();
     if (!pl) return SW_ERR_LAUNCH;
     const unsigned evf = hipEventDisableTiming;
-    bool ok = hipStreamCreateWithFlags(&pl->copy, hipStreamNonBlocking) == hipSuccess &&
+    // The copy stream is created with the HIGHEST priority the device offers: streams of one
+    // priority share a small pool of hardware queues, and a copy stream that lands on the hardware
+    // queue of the caller's (normal-priority) stream has its 64 KB H2D queued BEHIND the rollout
+    // kernel it is meant to run ahead of -- the host then waits a whole kernel for every copy
+    // (measured: the 4th pipeline of a process ran its iterations in 2.15 ms instead of 0.80,
+    // profiles/r03_a_outlier_probe.log).  Another priority class is another queue pool.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    bool ok = hipStreamCreateWithPriority(&pl->copy, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
               hipHostMalloc((void **)&pl->flag_host, 64, hipHostMallocMapped | hipHostMallocCoherent) ==
                   hipSuccess;
     if (ok) {

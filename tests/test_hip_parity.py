@@ -137,7 +137,9 @@ def test_gym_surface_step_for_step(sw, golden):
     assert abs(total - 756.1082843556578) < 1e-6   # SURVEY App. C anchor
     env.close()
     with pytest.raises(AssertionError):          # wrong action length, like the reference's check
-        sw.SwimmerEnv().step([0.0])
+        short = sw.SwimmerEnv()
+        short.reset()
+        short.step([0.0])
 
 
 def test_single_env_handle_matches_the_batched_step(sw, golden):
@@ -288,6 +290,31 @@ def test_rollout_batch_vs_oracle_and_moments(sw, kernel):
         ref2 = [oracle.rollout(op, 20, pol[r], state0=ref_traj[r, -1])[0] for r in range(R)]
         ret2 = sw.kernels.rollout(p, 20, torch.as_tensor(pol, device=dev), state0=fin)
         assert np.abs(ret2.cpu().numpy() - np.array(ref2)).max() <= 1e-9
+
+
+@pytest.mark.parametrize("n,R,H", [(3, 200, 333), (6, 70, 257), (6, 4096, 130), (7, 129, 300), (8, 65, 131)])
+def test_covariance_pass_on_ragged_tiles(sw, n, R, H):
+    """sw_traj_moments_f64 (np.mean / np.cov over the saved states, ars_agent.py:180-182) on sizes
+    that do not divide its tiles: partial last column tile, partial last step tile, an odd number
+    of steps for the two-step prefetch.  n >= 6 runs the form that splits a tile's sums over the four
+    waves of a workgroup; n = 3 the one-wave-per-column form.  Against float64 NumPy on the same
+    states; same bits on a second pass."""
+    d = 2 * n + 2
+    rs = np.random.RandomState(100 * n + R)
+    x = rs.randn(H, d, R) * rs.uniform(0.1, 3.0, (1, d, 1))
+    x[:, 2::2, :] += np.pi / 2
+    traj = torch.as_tensor(x, device="cuda:0")
+    p = sw.SwParams.make(n)
+    acc = sw.kernels.traj_moments(p, traj)[:1 + d + d * d].cpu().numpy()
+    c = np.zeros(d)
+    c[2::2] = np.pi / 2
+    y = x.transpose(0, 2, 1).reshape(-1, d) - c
+    assert acc[0] == R * H
+    assert np.allclose(acc[1:1 + d], y.sum(0), rtol=1e-11, atol=1e-9)
+    got, want = acc[1 + d:].reshape(d, d), y.T @ y
+    assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    assert np.array_equal(got, got.T)                           # mirrored from the upper triangle
+    assert np.array_equal(acc, sw.kernels.traj_moments(p, traj)[:1 + d + d * d].cpu().numpy())
 
 
 def test_edge_cases(sw):
