@@ -470,10 +470,10 @@ struct CovTiling {
     int32_t tchunk;
 };
 
-// Long chains (D >= 14, n >= 6) in 256-thread workgroups: the D (D + 1) / 2 + D sums do not fit one
+// Long chains (D >= 12, n >= 5) in 256-thread workgroups: the D (D + 1) / 2 + D sums do not fit one
 // lane's registers, so the four waves of the workgroup work on the SAME 64 rollouts and split the
 // sums between them (moments_split): a tile is 64 rollouts wide and four times as long.
-__host__ __device__ constexpr bool cov_split(int D, int block) { return D >= 14 && block >= 256; }
+__host__ __device__ constexpr bool cov_split(int D, int block) { return D >= 12 && block >= 256; }
 
 CovTiling cov_tiling(int64_t n_roll, int32_t H, int block, int D)
 {
@@ -605,31 +605,50 @@ __host__ __device__ constexpr int pair_col(int D, int p)
     return f + p;
 }
 
-template <int D, int WV>
+// item Q of the tile's sums, with every index a compile-time constant (a loop variable, even
+// fully unrolled, left the pair lookup to the optimiser, which put x[] and acc[] in scratch)
+template <int D, int Q>
+__device__ __forceinline__ void moments_item_add(double &a, const double (&x)[D])
+{
+    if constexpr (Q < D) {
+        a += x[Q];
+    } else {
+        constexpr int f = pair_row(D, Q - D), g = pair_col(D, Q - D);
+        a = __builtin_fma(x[f], x[g], a);
+    }
+}
+
+template <int D, int Q>
+__device__ __forceinline__ void moments_item_store(double v, double *__restrict__ tile_row)
+{
+    if constexpr (Q < D) {
+        tile_row[Q] = v;
+    } else {
+        constexpr int f = pair_row(D, Q - D), g = pair_col(D, Q - D);
+        tile_row[D + f * D + g] = v;   // upper triangle only
+    }
+}
+
+template <int D, int WV, int... I>
 __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double *__restrict__ traj,
                                                    double *__restrict__ tile_row, int64_t bx, int32_t t0,
-                                                   int32_t t1)
+                                                   int32_t t1, std::integer_sequence<int, I...>)
 {
-    constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4;
-    constexpr int Q0 = WV * PER, Q1 = (Q0 + PER < ITEMS) ? Q0 + PER : ITEMS;
+    constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4, Q0 = WV * PER;
+    constexpr int CNT = (int)sizeof...(I);   // = min(PER, ITEMS - Q0)
+    // the lowest state column this wave multiplies: columns below it are never loaded
+    constexpr int JMIN = (Q0 < D) ? 0 : pair_row(D, Q0 - D);
     const int l = threadIdx.x % kWave;
     const int64_t r = bx * kWave + l;
-    double acc[PER];
+    double acc[CNT];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) acc[q] = 0.0;
+    for (int q = 0; q < CNT; ++q) acc[q] = 0.0;
     auto load = [&](double (&x)[D], int32_t t) {
         const double *tp = traj + (int64_t)t * D * n_roll + r;
 #pragma unroll
-        for (int j = 0; j < D; ++j) {   // columns this wave never multiplies are dropped by the compiler
+        for (int j = JMIN; j < D; ++j) {
             const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
             x[j] = tp[(int64_t)j * n_roll] - c;
-        }
-    };
-    auto add = [&](const double (&x)[D]) {
-#pragma unroll
-        for (int q = Q0; q < Q1; ++q) {
-            if (q < D) acc[q - Q0] += x[q];
-            else acc[q - Q0] = __builtin_fma(x[pair_row(D, q - D)], x[pair_col(D, q - D)], acc[q - Q0]);
         }
     };
     if (r < n_roll && t0 < t1) {
@@ -637,21 +656,27 @@ __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double 
         load(xa, t0);
         for (int32_t t = t0; t < t1; t += 2) {
             if (t + 1 < t1) load(xb, t + 1);
-            add(xa);
+            (moments_item_add<D, Q0 + I>(acc[I], xa), ...);
             if (t + 2 < t1) load(xa, t + 2);
-            if (t + 1 < t1) add(xb);
+            if (t + 1 < t1) (moments_item_add<D, Q0 + I>(acc[I], xb), ...);
         }
     }
 #pragma unroll
-    for (int q = Q0; q < Q1; ++q) {
-        double v = acc[q - Q0];
+    for (int q = 0; q < CNT; ++q) {
 #pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-        if (l == 0) {
-            if (q < D) tile_row[q] = v;
-            else tile_row[D + pair_row(D, q - D) * D + pair_col(D, q - D)] = v;   // upper triangle only
-        }
+        for (int off = kWave / 2; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, kWave);
     }
+    if (l == 0) (moments_item_store<D, Q0 + I>(acc[I], tile_row), ...);
+}
+
+template <int D, int WV>
+__device__ __forceinline__ void moments_split_part(int64_t n_roll, const double *__restrict__ traj,
+                                                   double *__restrict__ tile_row, int64_t bx, int32_t t0,
+                                                   int32_t t1)
+{
+    constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4, Q0 = WV * PER;
+    constexpr int CNT = (Q0 + PER <= ITEMS) ? PER : ITEMS - Q0;
+    moments_split_wave<D, WV>(n_roll, traj, tile_row, bx, t0, t1, std::make_integer_sequence<int, CNT>{});
 }
 
 template <int D>
@@ -659,10 +684,10 @@ __device__ __forceinline__ void moments_split(int64_t n_roll, const double *__re
                                               double *__restrict__ tile_row, int64_t bx, int32_t t0, int32_t t1)
 {
     switch (threadIdx.x / kWave) {   // wave-uniform
-    case 0: moments_split_wave<D, 0>(n_roll, traj, tile_row, bx, t0, t1); break;
-    case 1: moments_split_wave<D, 1>(n_roll, traj, tile_row, bx, t0, t1); break;
-    case 2: moments_split_wave<D, 2>(n_roll, traj, tile_row, bx, t0, t1); break;
-    default: moments_split_wave<D, 3>(n_roll, traj, tile_row, bx, t0, t1); break;
+    case 0: moments_split_part<D, 0>(n_roll, traj, tile_row, bx, t0, t1); break;
+    case 1: moments_split_part<D, 1>(n_roll, traj, tile_row, bx, t0, t1); break;
+    case 2: moments_split_part<D, 2>(n_roll, traj, tile_row, bx, t0, t1); break;
+    default: moments_split_part<D, 3>(n_roll, traj, tile_row, bx, t0, t1); break;
     }
 }
 
