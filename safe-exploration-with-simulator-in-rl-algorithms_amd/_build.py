@@ -8,8 +8,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SWIMMER_HIP_LIB") or os.path.join(CSRC, "libswimmer_hip.so")  # override: experiments
 SOURCES = ["swimmer_kernels.hip", "host_rng.cpp", "direct_comm.cpp"]
 HEADERS = ["rlglue_env.cpp", os.path.join("..", "..", "include", "rlglue_swimmer.h"),
-           "swimmer_device.h", "swimmer_quad3.h", "swimmer_row.h", "swimmer_row_fused.h", "swimmer_twin.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+           "swimmer_device.h", "swimmer_quad3.h", "swimmer_oct3.h", "swimmer_row.h", "swimmer_row_fused.h", "swimmer_twin.h", os.path.join("..", "..", "include", "swimmer_hip.h")]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("SWIMMER_HIPCC_EXTRA", "").split()
 LINK_LIBS = ["-ldl"]   # direct_comm.cpp resolves RCCL at run time
 
 

@@ -241,6 +241,50 @@ __device__ __forceinline__ void angle_keep_reduced(Angle &A, double &thmax, doub
         : "vcc");
 }
 
+// angle_keep_reduced for lanes that keep sb SIGNED by a per-lane role sign sigma = +-1
+// (swimmer_oct3.h: A.sb holds sigma sin(K pi/2)): the quarter-turn rotation of (sa, sigma sb) by k
+// turns is the rotation by sigma k, i.e. the odd-k terms take the factor sigma.  One more multiply
+// on the rare path, the hot path (compare + untaken branch) is the same.
+__device__ __forceinline__ void angle_keep_reduced_signed(Angle &A, double &thmax, double magic, double sigma)
+{
+    double t0, t1, p, w;
+    int q, q1;
+    asm volatile(
+        "v_cmp_gt_f64_e64 vcc, |%[r]|, %[lim]\n\t"
+        "s_cbranch_vccnz .Lsw_renorm_%=\n"
+        ".Lsw_reduced_%=:\n\t"
+        ".subsection 1\n"
+        ".Lsw_renorm_%=:\n\t"
+        "v_fma_f64 %[t1], %[r], %[c2opi], %[magic]\n\t"     // k + magic
+        "v_add_f64 %[t0], %[t1], -%[magic]\n\t"             // k = rint(r * 2/pi)
+        "v_fma_f64 %[r], -%[t0], %[hi], %[r]\n\t"           // exact
+        "v_fma_f64 %[r], -%[t0], %[lo], %[r]\n\t"
+        "v_add_f64 %[kd], %[kd], %[t0]\n\t"
+        "v_cvt_i32_f64_e32 %[q], %[t0]\n\t"
+        "v_and_b32_e32 %[q1], 1, %[q]\n\t"
+        "v_and_b32_e32 %[q], 2, %[q]\n\t"
+        "v_cvt_f64_i32_e32 %[t0], %[q]\n\t"                 // 0 or 2
+        "v_add_f64 %[t0], 1.0, -%[t0]\n\t"                  // u = cos / sin of the even part
+        "v_cvt_f64_i32_e32 %[t1], %[q1]\n\t"                // odd: 0 or 1
+        "v_mul_f64 %[p], %[sa], %[t0]\n\t"
+        "v_mul_f64 %[w], %[sb], %[t0]\n\t"
+        "v_add_f64 %[t0], 1.0, -%[t1]\n\t"                  // even: 1 or 0
+        "v_mul_f64 %[t1], %[t1], %[sig]\n\t"                // odd, signed by the lane's role
+        "v_mul_f64 %[sa], %[t0], %[p]\n\t"
+        "v_mul_f64 %[sb], %[t0], %[w]\n\t"
+        "v_fma_f64 %[sa], -%[t1], %[w], %[sa]\n\t"          // odd: (sa, sb~) <- (-sigma sb~ u, sigma sa u)
+        "v_fma_f64 %[sb], %[t1], %[p], %[sb]\n\t"
+        "v_fma_f64 %[t0], %[kd], %[hi], %[r]\n\t"
+        "v_max_f64 %[thmax], %[thmax], |%[t0]|\n\t"
+        "s_branch .Lsw_reduced_%=\n\t"
+        ".subsection 0"
+        : [r] "+v"(A.r), [kd] "+v"(A.kd), [sa] "+v"(A.sa), [sb] "+v"(A.sb), [thmax] "+v"(thmax),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [p] "=&v"(p), [w] "=&v"(w), [q] "=&v"(q), [q1] "=&v"(q1)
+        : [lim] "s"(kPio4), [c2opi] "s"(0.63661977236758134308), [hi] "s"(kPio2Hi),
+          [lo] "s"(kPio2Lo), [magic] "v"(magic), [sig] "v"(sigma)
+        : "vcc");
+}
+
 __device__ __forceinline__ Angle angle_make(double theta)
 {
     Angle A{theta, 0.0, 1.0, 0.0};

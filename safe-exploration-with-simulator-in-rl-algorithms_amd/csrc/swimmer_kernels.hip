@@ -33,6 +33,7 @@
 #include "../../include/swimmer_hip.h"
 #include "swimmer_device.h"
 #include "swimmer_quad3.h"
+#include "swimmer_oct3.h"
 #include "swimmer_row.h"
 #include "swimmer_twin.h"
 
@@ -50,12 +51,17 @@
 #ifndef SW_TRAJ_STORE_AUX
 #define SW_TRAJ_STORE_AUX 16
 #endif
+// n = 3 rollouts: the mirror-quad kernel (swimmer_oct3.h) by default, or the quad kernel
+#ifndef SW_N3_DEFAULT_OCT
+#define SW_N3_DEFAULT_OCT false
+#endif
 
 namespace {
 
 constexpr int kWave = 64;
 constexpr int kStepBlock = 256;
 constexpr int kRollBlock = 64;   // one wave per workgroup: every wave gets a SIMD to itself
+constexpr int kOctBlock = 128;   // mirror-quad kernel: 8 rollouts per wave, 16 (= one V2 moment row) per workgroup
 constexpr int kMomGroup = 16;    // rollouts per V2 moment row (same partition in every kernel)
 constexpr int64_t kQuadMaxRollouts = 16384;  // above this every SIMD already has a wave
 constexpr int64_t kRowMaxRollouts = 8192;    // row kernel (n >= 4): 4 rollouts per wave
@@ -1058,6 +1064,193 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
 }
 
 // ------------------------------------------------------------------------------------
+// n = 3 with lane roles (swimmer_oct3.h): two mirror quads per rollout, 8 rollouts per wave, two
+// waves = 16 rollouts = one V2 moment row per 128-thread workgroup.
+template <bool ARS, bool TRAJ, bool MOM>
+__global__ void __launch_bounds__(kOctBlock)
+rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict__ policies,
+                    const double *__restrict__ deltas, int64_t dir_begin, double nu,
+                    const double *__restrict__ mean, const double *__restrict__ inv_std,
+                    const double *__restrict__ state0, double *__restrict__ returns,
+                    double *__restrict__ traj, double *__restrict__ final_state,
+                    double *__restrict__ moments, int32_t *__restrict__ status, SideJob side)
+{
+    side_flag(side);
+    if (blockIdx.x >= side.first_cov_block) {   // a covariance workgroup riding along (uniform)
+        side_cov_tile<8, kOctBlock>(side);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);   // as in the quad kernel
+    constexpr int D = 8, M = 2;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int q = lane & 3;
+    const int seg = (q == 3) ? 0 : q;              // lane 3 of a quad mirrors lane 0
+    const bool cosine = (lane & 8) != 0;           // quad B of the rollout: cosine / Gdot_y roles
+    const int64_t r_raw = (int64_t)blockIdx.x * kMomGroup + wave * 8 + (lane >> 4) * 2 + ((lane >> 2) & 1);
+    const bool valid = r_raw < n_roll;
+    const int64_t r = valid ? r_raw : n_roll - 1;  // surplus rollouts recompute the last one
+    const sw::OctLane O = sw::oct3_lane(C, seg, cosine);
+    const int cth = 2 + 2 * seg, cthd = 3 + 2 * seg;
+
+    // this lane's policy row in its rotated order [Gdx, Gdy, th_i, thd_i, th_i1, thd_i1, th_i2, thd_i2]
+    const int seg1 = (seg + 1) % 3, seg2 = (seg + 2) % 3;
+    const int cols[D] = {0, 1, cth, cthd, 2 + 2 * seg1, 3 + 2 * seg1, 2 + 2 * seg2, 3 + 2 * seg2};
+    double V[D], nbias;
+    load_policy_row<D, M, ARS>(ARS ? policies : policies + r * (M * D),
+                               ARS ? deltas + (dir_begin + (r >> 1)) * (M * D) : nullptr,
+                               (r & 1) ? -1.0 : 1.0, nu, mean, inv_std, C.c12, seg, cols, V, nbias);
+    // Gdot in the roles: Pu = the component this quad integrates, Pv = its partner's
+    const double VPu = cosine ? V[1] : V[0], VPv = cosine ? V[0] : V[1];
+
+    double gdx = 0.0, gdy = 0.0, th = kHalfPi, thd = 0.0;
+    if (state0) {
+        gdx = state0[r];
+        gdy = state0[n_roll + r];
+        th = state0[(int64_t)cth * n_roll + r];
+        thd = state0[(int64_t)cthd * n_roll + r];
+    }
+    double Pu = cosine ? gdy : gdx, Pv = cosine ? gdx : gdy;
+
+    // trajectory cells through a buffer resource (as in the quad kernel); quad A records theta,
+    // thetadot and Gdot_x, quad B Gdot_y; every other lane's store is dropped by the range check
+    const uint32_t kDrop = 0xfffffff0u;
+    const bool rec = !cosine && q < 3;
+    const uint32_t off_th = rec ? (uint32_t)(((int64_t)cth * n_roll + r) * 8) : kDrop;
+    const uint32_t off_thd = rec ? (uint32_t)(((int64_t)cthd * n_roll + r) * 8) : kDrop;
+    const uint32_t off_g = (q == 0) ? (uint32_t)(((int64_t)(cosine ? 1 : 0) * n_roll + r) * 8) : kDrop;
+    const uint32_t slab = (uint32_t)(D * n_roll * 8);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        traj, 0, TRAJ ? (int)(uint32_t)((int64_t)H * slab) : 0, 0x00020000);
+    uint32_t soff = 0;
+    auto store_cell = [&](double v, uint32_t voff) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        union { double d; v2i i; } u;
+        u.d = v;
+        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
+    };
+
+    sw::Angle A = sw::angle_make(th);
+    A.sb *= O.sigma;                       // kept signed by the role (swimmer_oct3.h)
+    double thmax = 0.0, det = 1.0;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
+    double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
+    double w1 = sw::dpp_f64<sw::kDppNext1>(thd), w2 = sw::dpp_f64<sw::kDppNext2>(thd);
+    double Th = __builtin_fma(V[2], th, nbias);
+    Th = __builtin_fma(V[4], sw::dpp_f64<sw::kDppNext1>(th), Th);
+    Th = __builtin_fma(V[6], sw::dpp_f64<sw::kDppNext2>(th), Th);
+    const double hV2 = C.h * V[2], hV4 = C.h * V[4], hV6 = C.h * V[6];
+    double magic = 6755399441055744.0;   // 1.5 * 2^52, pinned in a VGPR pair for the re-normalisation
+    double sigma = O.sigma;
+    asm volatile("" : "+v"(magic), "+v"(sigma));
+    sw::OctGeo G = sw::oct3_geometry(A, O), Gn;
+    auto one_step = [&](const sw::OctGeo &Gc, sw::OctGeo &Gx) {
+        double tq = __builtin_fma(VPu, Pu, Th);
+        tq = __builtin_fma(VPv, Pv, tq);
+        tq = __builtin_fma(V[3], thd, tq);
+        tq = __builtin_fma(V[5], w1, tq);
+        tq = __builtin_fma(V[7], w2, tq);
+        Th = __builtin_fma(hV2, thd, Th);
+        Th = __builtin_fma(hV4, w1, Th);
+        Th = __builtin_fma(hV6, w2, Th);
+        A.r = __builtin_fma(C.h, thd, A.r);
+        sw::angle_keep_reduced_signed(A, thmax, magic, sigma);
+        const double th_next = sw::angle_theta(A);
+        Gx = sw::oct3_geometry(A, O);
+        det = sw::oct3_dynamics(C, O, Gc, Pu, Pv, thd, w1, w2, tq);
+        th = th_next;
+        m1g += Pu;
+        if (TRAJ) {
+            store_cell(th, off_th);
+            store_cell(thd, off_thd);
+            store_cell(Pu, off_g);
+            soff += slab;
+        }
+        if (MOM) {
+            const double a = th - kHalfPi;
+            m1th += a;
+            m2th = __builtin_fma(a, a, m2th);
+            m1thd += thd;
+            m2thd = __builtin_fma(thd, thd, m2thd);
+            m2g = __builtin_fma(Pu, Pu, m2g);
+        }
+        w1 = sw::dpp_f64<sw::kDppNext1>(thd);
+        w2 = sw::dpp_f64<sw::kDppNext2>(thd);
+        Pv = sw::dpp_row_f64<sw::kDppRowRor8>(Pu);
+    };
+    int32_t t = 0;
+    for (; t + 4 <= H; t += 4) {
+        one_step(G, Gn);
+        one_step(Gn, G);
+        one_step(G, Gn);
+        one_step(Gn, G);
+    }
+    for (; t + 2 <= H; t += 2) {
+        one_step(G, Gn);
+        one_step(Gn, G);
+    }
+    if (t < H) one_step(G, Gn);
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
+
+    // ---- per-rollout outputs: quad A lanes 0..2 hold (theta, thetadot), A lane 0 Gdot_x, B lane 0 Gdot_y
+    int code = ((det > 0.0) ? 0 : SW_STATUS_SINGULAR) |
+               ((isfinite(th) && isfinite(thd) && isfinite(Pu) && isfinite(Pv)) ? 0 : SW_STATUS_NONFINITE) |
+               ((thmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
+    code |= __builtin_amdgcn_mov_dpp(code, sw::kDppNext1, 0xf, 0xf, true) |
+            __builtin_amdgcn_mov_dpp(code, sw::kDppNext2, 0xf, 0xf, true);
+    code |= __builtin_amdgcn_mov_dpp(code, sw::kDppRowRor8, 0xf, 0xf, true);
+    const double sg_other = sw::dpp_row_f64<sw::kDppRowRor8>(m1g);   // on A: sum Gdot_y
+    if (valid && !cosine && q == 0) {
+        const double total = __builtin_fma(C.dirx, m1g, C.diry * sg_other);
+        returns[r] = (code & SW_STATUS_RANGE) ? __builtin_nan("") : total;
+        if (status) status[r] = code;
+    }
+    if (final_state && valid) {
+        if (rec) {
+            final_state[(int64_t)cth * n_roll + r] = th;
+            final_state[(int64_t)cthd * n_roll + r] = thd;
+        }
+        if (q == 0) final_state[(int64_t)(cosine ? 1 : 0) * n_roll + r] = Pu;
+    }
+    if (MOM) {
+        __shared__ double shm[kOctBlock / kWave][16][6];
+        if (!valid) m1th = m2th = m1thd = m2thd = m1g = m2g = 0.0;
+        // sum over the 8 rollouts of the wave, per (quad half, segment) lane: lane bits 2, 4, 5
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int off = (k == 0) ? 4 : (k == 1 ? 16 : 32);
+            m1th += __shfl_xor(m1th, off, kWave);
+            m2th += __shfl_xor(m2th, off, kWave);
+            m1thd += __shfl_xor(m1thd, off, kWave);
+            m2thd += __shfl_xor(m2thd, off, kWave);
+            m1g += __shfl_xor(m1g, off, kWave);
+            m2g += __shfl_xor(m2g, off, kWave);
+        }
+        if (lane < 16) {
+            shm[wave][lane][0] = m1th;
+            shm[wave][lane][1] = m2th;
+            shm[wave][lane][2] = m1thd;
+            shm[wave][lane][3] = m2thd;
+            shm[wave][lane][4] = m1g;
+            shm[wave][lane][5] = m2g;
+        }
+        __syncthreads();
+        // row lanes 0..2: segments (quad A); row lane 0: Gdot_x sums; row lane 8: Gdot_y sums (quad B)
+        if (tid < 3) {
+            double *row = moments + (int64_t)blockIdx.x * (2 * D);
+            row[2 + 2 * tid] = shm[0][tid][0] + shm[1][tid][0];
+            row[D + 2 + 2 * tid] = shm[0][tid][1] + shm[1][tid][1];
+            row[3 + 2 * tid] = shm[0][tid][2] + shm[1][tid][2];
+            row[D + 3 + 2 * tid] = shm[0][tid][3] + shm[1][tid][3];
+            if (tid < 2) {
+                const int src = tid * 8;
+                row[tid] = shm[0][src][4] + shm[1][src][4];
+                row[D + tid] = shm[0][src][5] + shm[1][src][5];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // n = 4..8, one segment per lane, one rollout per 16-lane DPP row (swimmer_row.h).
 // 256-thread workgroups: 4 waves x 4 rows = 16 rollouts = one V2 moment row.
 template <int N, bool ARS, bool TRAJ, bool MOM>
@@ -1520,6 +1713,25 @@ __global__ void __launch_bounds__(kWave) issue_probe_kernel(int32_t trips, int32
         }                                                                                        \
     } while (0)
 
+#define SW_DISPATCH_OCT(ARS, HAS_TRAJ, HAS_MOM, STREAM, ...)                                    \
+    do {                                                                                         \
+        if (HAS_TRAJ) {                                                                          \
+            if (HAS_MOM)                                                                         \
+                hipLaunchKernelGGL((rollout_oct3_kernel<ARS, true, true>), dim3(grid),           \
+                                   dim3(kOctBlock), 0, STREAM, __VA_ARGS__);                     \
+            else                                                                                 \
+                hipLaunchKernelGGL((rollout_oct3_kernel<ARS, true, false>), dim3(grid),          \
+                                   dim3(kOctBlock), 0, STREAM, __VA_ARGS__);                     \
+        } else {                                                                                 \
+            if (HAS_MOM)                                                                         \
+                hipLaunchKernelGGL((rollout_oct3_kernel<ARS, false, true>), dim3(grid),          \
+                                   dim3(kOctBlock), 0, STREAM, __VA_ARGS__);                     \
+            else                                                                                 \
+                hipLaunchKernelGGL((rollout_oct3_kernel<ARS, false, false>), dim3(grid),         \
+                                   dim3(kOctBlock), 0, STREAM, __VA_ARGS__);                     \
+        }                                                                                        \
+    } while (0)
+
 // Kernel choice for rollouts: the quad (segment-per-lane) kernel while it still finds idle
 // SIMDs, the lane-per-rollout kernel beyond; sw_params.flags can force either.
 bool use_quad3(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
@@ -1531,6 +1743,17 @@ bool use_quad3(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
     if (n_roll >= ((int64_t)1 << 25)) return false;
     if (p->flags & SW_FLAG_ROLLOUT_QUAD) return true;
     return n_roll <= kQuadMaxRollouts;
+}
+
+// n = 3 with lane roles (two mirror quads per rollout, swimmer_oct3.h): 8 rollouts per wave, so it
+// keeps one wave per SIMD up to 8192 rollouts; beyond that the quad kernel (16 per wave) takes over.
+// SWIMMER_N3_KERNEL=quad|oct overrides the default (measurement knob).
+constexpr int64_t kOctMaxRollouts = 8192;
+bool use_oct3(const sw_params *p, int64_t n_roll, int32_t H, bool with_traj)
+{
+    static const char *env = getenv("SWIMMER_N3_KERNEL");
+    const bool want = env ? (env[0] == 'o') : SW_N3_DEFAULT_OCT;
+    return want && n_roll <= kOctMaxRollouts && use_quad3(p, n_roll, H, with_traj);
 }
 
 // n = 4..8: the row (segment-per-lane) kernel while it still finds idle SIMDs.
@@ -1708,6 +1931,14 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
     if (!policies || !returns) return SW_ERR_NULL;
     if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
+    if (use_oct3(p, n_roll, H, traj != nullptr)) {
+        const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        SW_DISPATCH_OCT(false, traj != nullptr, moments != nullptr,
+                        (hipStream_t)stream, C, n_roll, H, policies, (const double *)nullptr,
+                        (int64_t)0, 0.0, mean, inv_std, state0, returns, traj, final_state,
+                        moments, status, kNoSide);
+        return launch_status();
+    }
     if (use_quad3(p, n_roll, H, traj != nullptr)) {
         const unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
         SW_DISPATCH_QUAD(false, traj != nullptr, moments != nullptr,
@@ -1758,6 +1989,17 @@ static int launch_ars_rollouts(const sw_params *p, int64_t dir_begin, int64_t n_
     if ((mean == nullptr) != (inv_std == nullptr)) return SW_ERR_NULL;
     const sw::Consts C = make_consts(p);
     const int64_t n_roll = 2 * n_dir;
+    if (use_oct3(p, n_roll, H, traj != nullptr)) {
+        unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        SideJob sj = side ? *side : kNoSide;
+        grid += side_attach_cov(sj, grid, kOctBlock, 2 * p->n + 2);
+        if (side_taken) *side_taken = side != nullptr;
+        SW_DISPATCH_OCT(true, traj != nullptr, moments != nullptr,
+                        (hipStream_t)stream, C, n_roll, H, policy, deltas, dir_begin, nu, mean,
+                        inv_std, (const double *)nullptr, returns, traj, (double *)nullptr,
+                        moments, status, sj);
+        return launch_status();
+    }
     if (use_quad3(p, n_roll, H, traj != nullptr)) {
         unsigned grid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
         SideJob sj = side ? *side : kNoSide;
@@ -1875,6 +2117,10 @@ static int launch_traj_moments(const sw_params *p, int64_t n_roll, int32_t H, co
         SW_DISPATCH_N(p->n, hipLaunchKernelGGL((traj_moments_kernel<2 * NN + 2, kRollBlock>), grid,
                                                dim3(kRollBlock), 0, (hipStream_t)stream, n_roll, H,
                                                traj, acc, t.nbx, t.tchunk));
+    } else if (block == kOctBlock) {   // owed by a mirror-quad launch (n = 3 only)
+        if (p->n != 3) return SW_ERR_SIZE;
+        hipLaunchKernelGGL((traj_moments_kernel<8, kOctBlock>), grid, dim3(kOctBlock), 0,
+                           (hipStream_t)stream, n_roll, H, traj, acc, t.nbx, t.tchunk);
     } else {
         SW_DISPATCH_N(p->n, hipLaunchKernelGGL((traj_moments_kernel<2 * NN + 2, kMomBlock>), grid,
                                                dim3(kMomBlock), 0, (hipStream_t)stream, n_roll, H,
@@ -1889,9 +2135,11 @@ int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H)
     const int d = 2 * p->n + 2;
     int64_t tiles = 0;
     if (n_roll > 0 && H > 0) {
-        const CovTiling a = cov_tiling(n_roll, H, kRollBlock, d), b = cov_tiling(n_roll, H, kMomBlock, d);
-        const int64_t ta = (int64_t)a.nbx * a.ny, tb = (int64_t)b.nbx * b.ny;
+        const CovTiling a = cov_tiling(n_roll, H, kRollBlock, d), b = cov_tiling(n_roll, H, kMomBlock, d),
+                        c = cov_tiling(n_roll, H, kOctBlock, d);
+        const int64_t ta = (int64_t)a.nbx * a.ny, tb = (int64_t)b.nbx * b.ny, tc = (int64_t)c.nbx * c.ny;
         tiles = ta > tb ? ta : tb;
+        tiles = tc > tiles ? tc : tiles;
     }
     return cov_sums(d) + 1 + tiles * (d + d * d);
 }
@@ -2217,9 +2465,10 @@ int sw_ars_iteration_rollouts_f64(sw_ars_pipeline *pl, int slot, const sw_params
             hipEventRecord(ev.first, main) != hipSuccess)
             return SW_ERR_LAUNCH;
     }
-    const bool quad = use_quad3(p, 2 * n_dir, H, traj != nullptr);
+    const bool oct = use_oct3(p, 2 * n_dir, H, traj != nullptr);
+    const bool quad = use_quad3(p, 2 * n_dir, H, traj != nullptr);   // (true for oct launches too)
     const bool row = !quad && use_row(p, 2 * n_dir, H, traj != nullptr);
-    const int block = quad ? kRollBlock : kMomBlock;   // kRowBlock == kMomBlock
+    const int block = oct ? kOctBlock : (quad ? kRollBlock : kMomBlock);   // kRowBlock == kMomBlock
     SideJob sj = kNoSide;
     sj.flag = pl->flag_dev;
     sj.flag_value = k;

@@ -1,0 +1,169 @@
+// swimmer_oct3.h -- the 3-segment rollout step with LANE ROLES: two mirror quads per rollout.
+//
+// swimmer_quad3.h spreads a rollout over one DPP quad (lane q = segment q) and every lane evaluates
+// BOTH minimax polynomials of its angle (sin and cos: 20 of the step's 124 instructions) and BOTH
+// barycentre sums.  Here a rollout owns two quads of a 16-lane DPP row, eight lanes apart:
+//
+//   quad A (row lanes 0-3 / 4-7)    evaluates the SINE of its segment's reduced angle and carries Gdot_x
+//   quad B (row lanes 8-11 / 12-15) evaluates the COSINE                              and carries Gdot_y
+//
+// with the SAME instruction stream: one Horner chain whose seven coefficients sit in per-lane
+// registers (sine set on A, cosine set on B), and `v_mov_b32_dpp row_ror:8` hands each lane its
+// partner's value (two moves per double).  Everything else of the step is computed by both quads,
+// each on its own copy of the state (they differ by rounding only, like the quad kernel's per-lane
+// Gdot copies), written in terms of
+//        u = the value this lane evaluated      (A: sin theta_i,  B: cos theta_i)
+//        v = its partner's                      (A: cos theta_i,  B: sin theta_i)
+//        Pu = the Gdot component this quad integrates (A: x, B: y),  Pv = the partner's
+// so that no lane-dependent code is needed: cos(th_i - th_k) = u u_k + v v_k is symmetric in the roles;
+// sin(th_k - th_i), the segment's normal velocity and everything linear in it change SIGN on B, and
+// that sign lives in the per-lane constants (OctLane).  The barycentre update comes out the same
+// on both quads:  Pu += (h k l / (n m)) sum_j g~_j u_j.
+//
+// Per step: 10 instructions of sin/cos + 2 moves + 4 of quarter-turn rotation instead of 20 + 4, one
+// barycentre sum instead of two, no per-lane select for the recorded Gdot component: 114 instead
+// of 124 instructions (scripts/isa_loop_stats.py).  The rollout's trajectory is quad A's copy of
+// (theta, thetadot, Gdot_x) and quad B's Gdot_y.
+//
+// Same equations as swimmer_device.h (derivation there).  sin(r) = r + r z p(z) is the fdlibm form;
+// cos(r) = 1 + z q(z) folds fdlibm's  1 - z/2 + z^2 c(z)  into one Horner chain with a single
+// final rounding at magnitude 1.
+#pragma once
+
+#include "swimmer_quad3.h"
+
+namespace sw {
+
+constexpr int kDppRowRor8 = 0x128;   // dpp_ctrl row_ror:8 -- lane L of a 16-lane row reads lane (L + 8) % 16
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Per-lane constants: Quad3Lane's with the role sign sigma (+1 on quad A, -1 on quad B) folded in
+// where the quantity is odd in the roles.
+struct OctLane {
+    double kvw0, kvw1, kvw2;   // sigma l vel_w(i, .)
+    double ka0, ka1, ka2;      // sigma Aw(i, .)
+    double kt1, kt2;           // sigma (-6 T(i, i1)), sigma (-6 T(i, i2))
+    double t1, t2, t12;        // unsigned: the matrix entries
+    double d0, d12, d1, d2;
+    double k[7];               // Horner coefficients of this lane's polynomial in z = r^2
+    double selS, selC;         // X = selS r + selC: r on sine lanes, 1 on cosine lanes
+    double sigma;
+};
+
+__device__ __forceinline__ OctLane oct3_lane(const Consts &C, int seg, bool cosine)
+{
+    const Quad3Lane L = quad3_lane(seg);
+    const double sg = cosine ? -1.0 : 1.0;
+    OctLane O;
+    O.kvw0 = sg * (L.vw0 * C.l);
+    O.kvw1 = sg * (L.vw1 * C.l);
+    O.kvw2 = sg * (L.vw2 * C.l);
+    O.ka0 = sg * L.a0;
+    O.ka1 = sg * L.a1;
+    O.ka2 = sg * L.a2;
+    O.kt1 = sg * L.t1;
+    O.kt2 = sg * L.t2;
+    O.t1 = L.t1;
+    O.t2 = L.t2;
+    O.t12 = L.t12;
+    O.d0 = L.d0;
+    O.d12 = L.d12;
+    O.d1 = L.d1;
+    O.d2 = L.d2;
+    // fdlibm k_sin.c / k_cos.c (public domain): sin r = r + r z (S1 + z (S2 + ... z S6)),
+    // cos r = 1 + z (-1/2 + z (C1 + ... z C6))
+    const double S[7] = {0.0, 1.58969099521155010221e-10, -2.50507602534068634195e-08,
+                         2.75573137070700676789e-06, -1.98412698298579493134e-04,
+                         8.33333333332248946124e-03, -1.66666666666666324348e-01};
+    const double Cc[7] = {-1.13596475577881948265e-11, 2.08757232129817482790e-09,
+                          -2.75573143513906633035e-07, 2.48015872894767294178e-05,
+                          -1.38888888888741095749e-03, 4.16666666666666019037e-02, -0.5};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) O.k[j] = cosine ? Cc[j] : S[j];
+    O.selS = cosine ? 0.0 : 1.0;
+    O.selC = cosine ? 1.0 : 0.0;
+    O.sigma = sg;
+    return O;
+}
+
+// The angle state of a lane: Angle with sb replaced by sigma sb (the rotation below wants it signed).
+struct OctGeo {
+    double u, v, u1, v1, u2, v2;
+    double cc1, cc2, cc12;   // cos(th_i - th_i1), cos(th_i - th_i2), cos(th_i1 - th_i2)
+    double f1, f2;           // sigma sin(th_i1 - th_i), sigma sin(th_i2 - th_i)
+};
+
+// Everything of a step that depends on the angles only.  A.sb holds sigma sin(K pi/2) here.
+__device__ __forceinline__ OctGeo oct3_geometry(const Angle &A, const OctLane &O)
+{
+    OctGeo G;
+    const double r = A.r, z = r * r;
+    double p = fma3(O.k[0], z, O.k[1]);
+    p = fma3(p, z, O.k[2]);
+    p = fma3(p, z, O.k[3]);
+    p = fma3(p, z, O.k[4]);
+    p = fma3(p, z, O.k[5]);
+    p = fma3(p, z, O.k[6]);
+    const double X = __builtin_fma(O.selS, r, O.selC);
+    const double own = __builtin_fma(X * z, p, X);          // sin r on A, cos r on B
+    const double other = dpp_row_f64<kDppRowRor8>(own);     // cos r on A, sin r on B
+    // quarter turns: (s, c) = rotation by K pi/2 of (sin r, cos r); in the roles
+    //   u = sa own + (sigma sb) other,   v = sa other - (sigma sb) own
+    G.u = __builtin_fma(A.sa, own, A.sb * other);
+    G.v = __builtin_fma(A.sa, other, -(A.sb * own));
+    G.u1 = dpp_f64<kDppNext1>(G.u);
+    G.v1 = dpp_f64<kDppNext1>(G.v);
+    G.u2 = dpp_f64<kDppNext2>(G.u);
+    G.v2 = dpp_f64<kDppNext2>(G.v);
+    G.cc1 = __builtin_fma(G.u, G.u1, G.v * G.v1);
+    G.cc2 = __builtin_fma(G.u, G.u2, G.v * G.v2);
+    G.cc12 = __builtin_fma(G.u1, G.u2, G.v1 * G.v2);
+    G.f1 = __builtin_fma(G.v, G.u1, -G.u * G.v1);
+    G.f2 = __builtin_fma(G.v, G.u2, -G.u * G.v2);
+    return G;
+}
+
+// The velocity-dependent part of one explicit-Euler step: updates Pu (this quad's Gdot component) and
+// thd; the caller exchanges Pv afterwards.  Returns det for the singularity check.
+__device__ __forceinline__ double oct3_dynamics(const Consts &C, const OctLane &O, const OctGeo &G,
+                                                double &Pu, double Pv, double &thd, double w1, double w2,
+                                                double tq_scaled)
+{
+    // g~ = sigma (normal velocity of this segment's centre)
+    double g = __builtin_fma(Pv, G.v, -Pu * G.u);
+    g = __builtin_fma(O.kvw0, thd, g);
+    g = __builtin_fma(O.kvw1 * G.cc1, w1, g);
+    g = __builtin_fma(O.kvw2 * G.cc2, w2, g);
+    const double g1 = dpp_f64<kDppNext1>(g), g2 = dpp_f64<kDppNext2>(g);
+    // this quad's barycentre sum: A: sum g_j sin th_j, B: -sum g_j cos th_j
+    const double su = __builtin_fma(g2, G.u2, __builtin_fma(g1, G.u1, g * G.u));
+    double cent = __builtin_fma(O.kt1 * (w1 * w1), G.f1, tq_scaled);
+    cent = __builtin_fma(O.kt2 * (w2 * w2), G.f2, cent);
+    double fric = O.ka0 * g;
+    fric = __builtin_fma(O.ka1 * G.cc1, g1, fric);
+    fric = __builtin_fma(O.ka2 * G.cc2, g2, fric);
+    double r0 = __builtin_fma(-C.six_k_m, fric, cent);
+    r0 = __builtin_fma(C.kl_m, thd, r0);
+    const double r1 = dpp_f64<kDppNext1>(r0), r2 = dpp_f64<kDppNext2>(r0);
+    const double a = O.t1 * G.cc1, b = O.t2 * G.cc2, e = O.t12 * G.cc12;
+    const double c00 = __builtin_fma(-e, e, O.d12);
+    const double c01 = __builtin_fma(b, e, -a * O.d2);
+    const double c02 = __builtin_fma(a, e, -b * O.d1);
+    const double det = __builtin_fma(O.d0, c00, __builtin_fma(a, c01, b * c02));
+    const double num = __builtin_fma(c00, r0, __builtin_fma(c01, r1, c02 * r2));
+    const double tdd = num * rcp_f64_1n(det);
+    // A: Gdot_x += (h k l / (n m)) sum g_j sin th_j;  B: Gdot_y -= ... sum g_j cos th_j: the same FMA
+    Pu = __builtin_fma(C.h_kl_nm, su, Pu);
+    thd = __builtin_fma(C.h, tdd, thd);
+    return det;
+}
+
+}  // namespace sw
