@@ -9,8 +9,11 @@
 //                              A two-envs-per-lane variant with 16-byte accesses measured SLOWER
 //                              (4.87 vs 5.62 TB/s: 90 VGPRs, fewer loads in flight) and was dropped.
 //   accel_kernel<N,TWIN>       accelerations only
-//   rollout_quad3_kernel       n = 3, H steps in one launch, ONE SEGMENT PER LANE (DPP quad per
-//                              rollout, swimmer_quad3.h): the latency form, instruction-issue bound
+//   rollout_oct3_kernel        n = 3, H steps in one launch, one segment per lane WITH LANE ROLES: two
+//                              mirror quads per rollout (sine / cosine, Gdot_x / Gdot_y;
+//                              swimmer_oct3.h): the latency form, instruction-issue bound; up to
+//                              8192 rollouts (one wave per SIMD)
+//   rollout_quad3_kernel       n = 3, one DPP quad per rollout (swimmer_quad3.h): 8193 .. 16384 rollouts
 //   rollout_row_kernel<N>      n = 4..8, one segment per lane, one rollout per 16-lane DPP row
 //                              (swimmer_row.h)
 //   rollout_kernel<N,ARS,TWIN> any n, ONE ROLLOUT PER LANE: the throughput form for batches that
@@ -53,7 +56,7 @@
 #endif
 // n = 3 rollouts: the mirror-quad kernel (swimmer_oct3.h) by default, or the quad kernel
 #ifndef SW_N3_DEFAULT_OCT
-#define SW_N3_DEFAULT_OCT false
+#define SW_N3_DEFAULT_OCT true
 #endif
 
 namespace {
@@ -1129,20 +1132,20 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
         __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
     };
 
-    sw::Angle A = sw::angle_make(th);
-    A.sb *= O.sigma;                       // kept signed by the role (swimmer_oct3.h)
+    // the angle in reduced form + the polynomial this lane currently evaluates (swimmer_oct3.h)
+    const int designation = cosine ? 1 : 0;
     double thmax = 0.0, det = 1.0;
-    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
+    sw::OctTrig A;
+    A.r = th;
+    A.kd = 0.0;
+    sw::oct3_renorm(A, designation, thmax);
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0, m1g = 0.0, m2g = 0.0;
     double w1 = sw::dpp_f64<sw::kDppNext1>(thd), w2 = sw::dpp_f64<sw::kDppNext2>(thd);
     double Th = __builtin_fma(V[2], th, nbias);
     Th = __builtin_fma(V[4], sw::dpp_f64<sw::kDppNext1>(th), Th);
     Th = __builtin_fma(V[6], sw::dpp_f64<sw::kDppNext2>(th), Th);
     const double hV2 = C.h * V[2], hV4 = C.h * V[4], hV6 = C.h * V[6];
-    double magic = 6755399441055744.0;   // 1.5 * 2^52, pinned in a VGPR pair for the re-normalisation
-    double sigma = O.sigma;
-    asm volatile("" : "+v"(magic), "+v"(sigma));
-    sw::OctGeo G = sw::oct3_geometry(A, O), Gn;
+    sw::OctGeo G = sw::oct3_geometry(A), Gn;
     auto one_step = [&](const sw::OctGeo &Gc, sw::OctGeo &Gx) {
         double tq = __builtin_fma(VPu, Pu, Th);
         tq = __builtin_fma(VPv, Pv, tq);
@@ -1153,9 +1156,8 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
         Th = __builtin_fma(hV4, w1, Th);
         Th = __builtin_fma(hV6, w2, Th);
         A.r = __builtin_fma(C.h, thd, A.r);
-        sw::angle_keep_reduced_signed(A, thmax, magic, sigma);
-        const double th_next = sw::angle_theta(A);
-        Gx = sw::oct3_geometry(A, O);
+        const double th_next = __builtin_fma(A.kd, sw::kPio2Hi, A.r);
+        Gx = sw::oct3_geometry(A);
         det = sw::oct3_dynamics(C, O, Gc, Pu, Pv, thd, w1, w2, tq);
         th = th_next;
         m1g += Pu;
@@ -1177,18 +1179,32 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
         w2 = sw::dpp_f64<sw::kDppNext2>(thd);
         Pv = sw::dpp_row_f64<sw::kDppRowRor8>(Pu);
     };
+    // Range check ONCE PER TRIP: will |r| stay inside [-pi/4, pi/4] for the next `steps` steps at the
+    // present angular velocity?  If any lane says no, all lanes re-normalise (no-op where |r| <= pi/4).
+    // What thetadot gains within a trip may carry r a little past pi/4: the polynomials are accurate
+    // to 1.4e-16 up to pi/4 + 0.03 (swimmer_oct3.h).
+    auto keep_reduced = [&](int steps) {
+        const double reach = __builtin_fma((double)steps * C.h, fabs(thd), fabs(A.r));
+        if (__builtin_expect(__any(reach > sw::kPio4), 0)) sw::oct3_renorm(A, designation, thmax);
+    };
     int32_t t = 0;
     for (; t + 4 <= H; t += 4) {
+        keep_reduced(4);
         one_step(G, Gn);
         one_step(Gn, G);
         one_step(G, Gn);
         one_step(Gn, G);
     }
     for (; t + 2 <= H; t += 2) {
+        keep_reduced(2);
         one_step(G, Gn);
         one_step(Gn, G);
     }
-    if (t < H) one_step(G, Gn);
+    if (t < H) {
+        keep_reduced(1);
+        one_step(G, Gn);
+    }
+    thmax = fmax(thmax, fabs(th));
     asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
 
     // ---- per-rollout outputs: quad A lanes 0..2 hold (theta, thetadot), A lane 0 Gdot_x, B lane 0 Gdot_y

@@ -20,10 +20,20 @@
 // that sign lives in the per-lane constants (OctLane).  The barycentre update comes out the same
 // on both quads:  Pu += (h k l / (n m)) sum_j g~_j u_j.
 //
-// Per step: 10 instructions of sin/cos + 2 moves + 4 of quarter-turn rotation instead of 20 + 4, one
-// barycentre sum instead of two, no per-lane select for the recorded Gdot component: 114 instead
-// of 124 instructions (scripts/isa_loop_stats.py).  The rollout's trajectory is quad A's copy of
-// (theta, thetadot, Gdot_x) and quad B's Gdot_y.
+// Quarter turns cost nothing per step either.  The angle is carried reduced, theta = r + K pi/2, and
+//        sin(r + K pi/2) = +sin r, +cos r, -sin r, -cos r   for K mod 4 = 0, 1, 2, 3
+//        cos(theta) = sin(theta + pi/2): the same table read at K + 1,
+// so a lane's DESIGNATED output (A: sin theta, B: cos theta) is one of the two polynomials of r with
+// a sign: the lane's coefficient set and the sign (in selS / selC) are state, re-chosen only when K
+// changes -- in the rare re-normalisation block, which is plain C++ here because it is entered from
+// a check made ONCE PER TRIP of four steps, not per step: |r| + 4 h |thetadot| > pi/4.  Between
+// two checks r may leave [-pi/4, pi/4] by what thetadot gains within a trip; the polynomials stay
+// accurate to 1.4e-16 up to pi/4 + 0.03 (1.2e-16 inside), checked against long-double libm.
+//
+// Per step: 10 instructions of sin/cos + 2 moves instead of 20 + 4 of rotation + 2 of range check,
+// one barycentre sum instead of two, no per-lane select for the recorded Gdot component
+// (scripts/isa_loop_stats.py).  The rollout's trajectory is quad A's copy of (theta, thetadot,
+// Gdot_x) and quad B's Gdot_y.
 //
 // Same equations as swimmer_device.h (derivation there).  sin(r) = r + r z p(z) is the fdlibm form;
 // cos(r) = 1 + z q(z) folds fdlibm's  1 - z/2 + z^2 c(z)  into one Horner chain with a single
@@ -53,10 +63,51 @@ struct OctLane {
     double kt1, kt2;           // sigma (-6 T(i, i1)), sigma (-6 T(i, i2))
     double t1, t2, t12;        // unsigned: the matrix entries
     double d0, d12, d1, d2;
-    double k[7];               // Horner coefficients of this lane's polynomial in z = r^2
-    double selS, selC;         // X = selS r + selC: r on sine lanes, 1 on cosine lanes
     double sigma;
 };
+
+// What a lane evaluates of its reduced angle: X (1 + z p(z)), z = r^2, X = selS r + selC.
+// Sine type: p = S1 + z (S2 + ... z S6), (selS, selC) = (sign, 0); cosine type: p = -1/2 + z (C1 +
+// ... z C6), (selS, selC) = (0, sign).  fdlibm k_sin.c / k_cos.c coefficients (public domain);
+// sin r = r + r z p(z) is the fdlibm form, cos r = 1 + z q(z) folds fdlibm's 1 - z/2 + z^2 c(z)
+// into one Horner chain with a single final rounding at magnitude 1.
+struct OctTrig {
+    double r, kd;      // theta = r + kd pi/2, kd an exact integer
+    double k[7];
+    double selS, selC;
+};
+
+// (Re)choose type and sign from K = kd and the lane's designation (0: sin theta, 1: cos theta).
+__device__ __forceinline__ void oct3_retype(OctTrig &T, int designation)
+{
+    const double S[7] = {0.0, 1.58969099521155010221e-10, -2.50507602534068634195e-08,
+                         2.75573137070700676789e-06, -1.98412698298579493134e-04,
+                         8.33333333332248946124e-03, -1.66666666666666324348e-01};
+    const double Cc[7] = {-1.13596475577881948265e-11, 2.08757232129817482790e-09,
+                          -2.75573143513906633035e-07, 2.48015872894767294178e-05,
+                          -1.38888888888741095749e-03, 4.16666666666666019037e-02, -0.5};
+    const int q = (int)T.kd + designation;      // |kd| < 2^31 inside the valid angle range
+    const bool cos_type = (q & 1) != 0;
+    const double sign = (q & 2) ? -1.0 : 1.0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) T.k[j] = cos_type ? Cc[j] : S[j];
+    T.selS = cos_type ? 0.0 : sign;
+    T.selC = cos_type ? sign : 0.0;
+}
+
+// Move whole quarter turns from r into kd and re-choose the polynomial (all lanes; a no-op where
+// |r| <= pi/4).  thmax <- max(thmax, |theta|): every way to a huge angle leads through here.
+__device__ __forceinline__ void oct3_renorm(OctTrig &T, int designation, double &thmax)
+{
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double km = __builtin_fma(T.r, 0.63661977236758134308, MAGIC);
+    const double k = km - MAGIC;
+    const double r = __builtin_fma(-k, kPio2Hi, T.r);      // exact
+    T.r = __builtin_fma(-k, kPio2Lo, r);
+    T.kd += k;
+    oct3_retype(T, designation);
+    thmax = fmax(thmax, fabs(__builtin_fma(T.kd, kPio2Hi, T.r)));
+}
 
 __device__ __forceinline__ OctLane oct3_lane(const Consts &C, int seg, bool cosine)
 {
@@ -78,47 +129,30 @@ __device__ __forceinline__ OctLane oct3_lane(const Consts &C, int seg, bool cosi
     O.d12 = L.d12;
     O.d1 = L.d1;
     O.d2 = L.d2;
-    // fdlibm k_sin.c / k_cos.c (public domain): sin r = r + r z (S1 + z (S2 + ... z S6)),
-    // cos r = 1 + z (-1/2 + z (C1 + ... z C6))
-    const double S[7] = {0.0, 1.58969099521155010221e-10, -2.50507602534068634195e-08,
-                         2.75573137070700676789e-06, -1.98412698298579493134e-04,
-                         8.33333333332248946124e-03, -1.66666666666666324348e-01};
-    const double Cc[7] = {-1.13596475577881948265e-11, 2.08757232129817482790e-09,
-                          -2.75573143513906633035e-07, 2.48015872894767294178e-05,
-                          -1.38888888888741095749e-03, 4.16666666666666019037e-02, -0.5};
-#pragma unroll
-    for (int j = 0; j < 7; ++j) O.k[j] = cosine ? Cc[j] : S[j];
-    O.selS = cosine ? 0.0 : 1.0;
-    O.selC = cosine ? 1.0 : 0.0;
     O.sigma = sg;
     return O;
 }
 
-// The angle state of a lane: Angle with sb replaced by sigma sb (the rotation below wants it signed).
 struct OctGeo {
     double u, v, u1, v1, u2, v2;
     double cc1, cc2, cc12;   // cos(th_i - th_i1), cos(th_i - th_i2), cos(th_i1 - th_i2)
     double f1, f2;           // sigma sin(th_i1 - th_i), sigma sin(th_i2 - th_i)
 };
 
-// Everything of a step that depends on the angles only.  A.sb holds sigma sin(K pi/2) here.
-__device__ __forceinline__ OctGeo oct3_geometry(const Angle &A, const OctLane &O)
+// Everything of a step that depends on the angles only.
+__device__ __forceinline__ OctGeo oct3_geometry(const OctTrig &T)
 {
     OctGeo G;
-    const double r = A.r, z = r * r;
-    double p = fma3(O.k[0], z, O.k[1]);
-    p = fma3(p, z, O.k[2]);
-    p = fma3(p, z, O.k[3]);
-    p = fma3(p, z, O.k[4]);
-    p = fma3(p, z, O.k[5]);
-    p = fma3(p, z, O.k[6]);
-    const double X = __builtin_fma(O.selS, r, O.selC);
-    const double own = __builtin_fma(X * z, p, X);          // sin r on A, cos r on B
-    const double other = dpp_row_f64<kDppRowRor8>(own);     // cos r on A, sin r on B
-    // quarter turns: (s, c) = rotation by K pi/2 of (sin r, cos r); in the roles
-    //   u = sa own + (sigma sb) other,   v = sa other - (sigma sb) own
-    G.u = __builtin_fma(A.sa, own, A.sb * other);
-    G.v = __builtin_fma(A.sa, other, -(A.sb * own));
+    const double r = T.r, z = r * r;
+    double p = fma3(T.k[0], z, T.k[1]);
+    p = fma3(p, z, T.k[2]);
+    p = fma3(p, z, T.k[3]);
+    p = fma3(p, z, T.k[4]);
+    p = fma3(p, z, T.k[5]);
+    p = fma3(p, z, T.k[6]);
+    const double X = __builtin_fma(T.selS, r, T.selC);
+    G.u = __builtin_fma(X * z, p, X);                  // sin theta on A, cos theta on B
+    G.v = dpp_row_f64<kDppRowRor8>(G.u);               // cos theta on A, sin theta on B
     G.u1 = dpp_f64<kDppNext1>(G.u);
     G.v1 = dpp_f64<kDppNext1>(G.v);
     G.u2 = dpp_f64<kDppNext2>(G.u);

@@ -209,6 +209,21 @@ def test_quad_eligible_batch_with_a_4gib_trajectory_buffer(sw):
     assert np.abs(traj[1000, :, ::97].cpu().numpy() - out["lane"][2]).max() <= 1e-7
 
 
+def test_quad_kernel_still_matches_the_reference(sw):
+    """n = 3 batches of up to 8192 rollouts run on the mirror-quad kernel (swimmer_oct3.h); the
+    one-quad-per-rollout kernel serves 8193 .. 16384 rollouts.  SWIMMER_N3_KERNEL=quad (read once
+    per process) makes it take the small batches too: the reference-golden rollout and ARS tests
+    once more, in a child process, on that kernel."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SWIMMER_N3_KERNEL="quad")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
+                          "-k", "rollouts_vs_reference_golden or ars_iterations_vs_reference or rollout_batch_vs_oracle"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
 def _traj_keys(t):
     return [x[:-len("_return")] for x in t.files if x.endswith("_return")]
 
