@@ -641,7 +641,7 @@ __device__ __forceinline__ void moments_item_store(double v, double *__restrict_
 template <int D, int WV, int... I>
 __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double *__restrict__ traj,
                                                    double *__restrict__ tile_row, int64_t bx, int32_t t0,
-                                                   int32_t t1, std::integer_sequence<int, I...>)
+                                                   int32_t t1, int32_t nap, std::integer_sequence<int, I...>)
 {
     constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4, Q0 = WV * PER;
     constexpr int CNT = (int)sizeof...(I);   // = min(PER, ITEMS - Q0)
@@ -668,6 +668,9 @@ __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double 
             (moments_item_add<D, Q0 + I>(acc[I], xa), ...);
             if (t + 2 < t1) load(xa, t + 2);
             if (t + 1 < t1) (moments_item_add<D, Q0 + I>(acc[I], xb), ...);
+            // riding along in a rollout launch that fills the chip: pace the loads so that this wave's
+            // requests do not crowd the CU's memory pipeline in front of the rollout waves' stores
+            for (int32_t z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
         }
     }
 #pragma unroll
@@ -681,22 +684,23 @@ __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double 
 template <int D, int WV>
 __device__ __forceinline__ void moments_split_part(int64_t n_roll, const double *__restrict__ traj,
                                                    double *__restrict__ tile_row, int64_t bx, int32_t t0,
-                                                   int32_t t1)
+                                                   int32_t t1, int32_t nap)
 {
     constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4, Q0 = WV * PER;
     constexpr int CNT = (Q0 + PER <= ITEMS) ? PER : ITEMS - Q0;
-    moments_split_wave<D, WV>(n_roll, traj, tile_row, bx, t0, t1, std::make_integer_sequence<int, CNT>{});
+    moments_split_wave<D, WV>(n_roll, traj, tile_row, bx, t0, t1, nap, std::make_integer_sequence<int, CNT>{});
 }
 
 template <int D>
 __device__ __forceinline__ void moments_split(int64_t n_roll, const double *__restrict__ traj,
-                                              double *__restrict__ tile_row, int64_t bx, int32_t t0, int32_t t1)
+                                              double *__restrict__ tile_row, int64_t bx, int32_t t0, int32_t t1,
+                                              int32_t nap)
 {
     switch (threadIdx.x / kWave) {   // wave-uniform
-    case 0: moments_split_part<D, 0>(n_roll, traj, tile_row, bx, t0, t1); break;
-    case 1: moments_split_part<D, 1>(n_roll, traj, tile_row, bx, t0, t1); break;
-    case 2: moments_split_part<D, 2>(n_roll, traj, tile_row, bx, t0, t1); break;
-    default: moments_split_part<D, 3>(n_roll, traj, tile_row, bx, t0, t1); break;
+    case 0: moments_split_part<D, 0>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
+    case 1: moments_split_part<D, 1>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
+    case 2: moments_split_part<D, 2>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
+    default: moments_split_part<D, 3>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
     }
 }
 
@@ -704,7 +708,7 @@ __device__ __forceinline__ void moments_split(int64_t n_roll, const double *__re
 template <int D, int BLOCK>
 __device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const double *__restrict__ traj,
                                              double *__restrict__ acc, int64_t bx, int32_t t0, int32_t t1,
-                                             uint32_t tile, uint32_t n_tiles)
+                                             uint32_t tile, uint32_t n_tiles, int32_t nap = 0)
 {
     // rows of the upper triangle per pass: as many as keep the accumulators (D + the rows' entries)
     // plus one state inside 256 VGPRs -- one pass up to D = 12, 2 / 3 / 4 passes for D = 14 / 16 / 18
@@ -714,7 +718,7 @@ __device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const do
     double *rows = acc + cov_sums(D) + 1;
     if constexpr (cov_split(D, BLOCK)) {
         static_assert(BLOCK == 4 * kWave, "moments_split: four waves per workgroup");
-        moments_split<D>(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1);
+        moments_split<D>(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1, nap);
     } else {
         __shared__ double sh[(BLOCK / kWave) * (D + JB * D)];
         MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1, sh);
@@ -779,6 +783,7 @@ struct SideJob {
     uint32_t cov_nbx;           // covariance tiles along the rollout axis
     uint32_t cov_tiles;         // covariance tiles in all
     int32_t cov_tchunk;         // steps per covariance tile
+    int32_t cov_nap;            // s_sleep rounds per two steps of a split tile (load pacing)
     int32_t cov_H;
     int64_t cov_rolls;
     const double *cov_traj;
@@ -792,7 +797,7 @@ __device__ __forceinline__ void side_cov_tile(const SideJob &sj)
     const uint32_t bx = b % sj.cov_nbx, by = b / sj.cov_nbx;
     const int32_t t0 = (int32_t)by * sj.cov_tchunk;
     moments_tile<D, BLOCK>(sj.cov_rolls, sj.cov_H, sj.cov_traj, sj.cov_acc, bx, t0,
-                           min(sj.cov_H, t0 + sj.cov_tchunk), b, sj.cov_tiles);
+                           min(sj.cov_H, t0 + sj.cov_tchunk), b, sj.cov_tiles, sj.cov_nap);
 }
 
 __device__ __forceinline__ void side_flag(const SideJob &sj)
@@ -1816,7 +1821,7 @@ int launch_status()
     return hipGetLastError() == hipSuccess ? SW_OK : SW_ERR_LAUNCH;
 }
 
-const SideJob kNoSide{nullptr, 0u, UINT32_MAX, 1u, 0u, 0, 0, 0, nullptr, nullptr};
+const SideJob kNoSide{nullptr, 0u, UINT32_MAX, 1u, 0u, 0, 0, 0, 0, nullptr, nullptr};
 
 // Attach a covariance pass over (cov_traj, cov_rolls, cov_H) to a launch of `roll_blocks` rollout
 // workgroups of `block` threads; returns the number of extra workgroups.
@@ -1831,6 +1836,8 @@ unsigned side_attach_cov(SideJob &sj, unsigned roll_blocks, int block, int sj_D)
     sj.cov_nbx = t.nbx;
     sj.cov_tchunk = t.tchunk;
     sj.cov_tiles = t.nbx * t.ny;
+    static const char *nap_env = getenv("SWIMMER_COV_NAP");   // measurement knob
+    sj.cov_nap = nap_env ? atoi(nap_env) : 0;
     return sj.cov_tiles;
 }
 

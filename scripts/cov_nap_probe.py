@@ -1,0 +1,28 @@
+"""n = 6, 2048 directions on one GPU (a rollout wave on every SIMD): rollout launch with the covariance
+pass riding along, for the load pacing given by SWIMMER_COV_NAP (read once per process).  Design aid."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import swimmer_amd as sw
+torch.cuda.set_stream(torch.cuda.Stream("cuda:0"))
+n, N, H = 6, 2048, 1000
+res = {}
+for tag, kw in (("capture only", dict(full_covariance=False, record_trajectories=True)),
+                ("capture + ride-along pass", dict(full_covariance=True))):
+    ep = sw.EnvParam("B", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("B", V1=False, n_iter=0, H=H, N=N, b=N, alpha=0.0075, nu=0.01, safe=False,
+                     threshold=0, initial_w="Zero")
+    a = sw.ARSAgent(ep, ap, seed=0, device="cuda:0", **kw)
+    for _ in range(4):
+        a.run_iteration_async(want_returns=False)
+        a.database._device_batches.clear()
+    torch.cuda.synchronize()
+    a._pipe.timing(1)
+    for _ in range(10):
+        a.run_iteration_async(want_returns=False)
+        a.database._device_batches.clear()
+    torch.cuda.synchronize()
+    res[tag] = a._pipe.rollout_ms()[0]
+    del a
+print(f"SWIMMER_COV_NAP={os.environ.get('SWIMMER_COV_NAP', '0'):>3}: " + ", ".join(f"{k} {v:.4f} ms" for k, v in res.items())
+      + f"; riding along costs {1e3 * (res['capture + ride-along pass'] - res['capture only']):+.1f} us", flush=True)
