@@ -1292,8 +1292,9 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     constexpr int D = 2 * N + 2, M = N - 1;
     const int tid = threadIdx.x;
     const int q = tid & 15;                        // lane inside the row
-    const bool owner = q < N;                      // lanes N..15 mirror lane 0
-    const int seg = owner ? q : 0;
+    const bool owner = q < N;                      // lanes 0..N-1 own the segments' cells
+    const bool cosine = q >= 8;                    // lane i + 8 mirrors lane i and evaluates the cosine
+    const int seg = ((q & 7) < N) ? (q & 7) : 0;   // lanes N..7 / N+8..15 mirror lane 0 / 8
     const int64_t r_raw = (int64_t)blockIdx.x * kMomGroup + (tid >> 4);
     const bool valid = r_raw < n_roll;
     const int64_t r = valid ? r_raw : n_roll - 1;  // surplus rows recompute the last rollout
@@ -1342,17 +1343,25 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     };
 
     double thmax = 0.0, pivmin_all = 1.0;
-    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
     double sgx = 0.0, sgy = 0.0, qgx = 0.0, qgy = 0.0;   // sums of Gdot and Gdot^2 over the steps
-    const sw::TrigK K = sw::trig_consts();
-    double magic = 6755399441055744.0;   // 1.5 * 2^52, pinned in a VGPR pair for angle_keep_reduced
-    asm volatile("" : "+v"(magic));
-    sw::Angle A = sw::angle_make(th);    // theta = r + K pi/2 (swimmer_device.h)
-    for (int32_t t = 0; t < H; ++t) {
+    // theta = r + K pi/2 and the polynomial this lane evaluates of r (swimmer_oct3.h, OctTrig)
+    const int designation = cosine ? 1 : 0;
+    sw::OctTrig A;
+    A.r = th;
+    A.kd = 0.0;
+    sw::oct3_renorm(A, designation, thmax);
+    for (int32_t t_trip = 0; t_trip < H; t_trip += 4) {
+        // range check once per trip of four steps (swimmer_oct3.h): will |r| stay inside
+        // [-pi/4, pi/4] at the present angular velocity?  If any lane says no, all re-normalise.
+        const double reach = __builtin_fma(4.0 * C.h, fabs(thd), fabs(A.r));
+        if (__builtin_expect(__any(reach > sw::kPio4), 0)) sw::oct3_renorm(A, designation, thmax);
+        const int32_t t_end = min(H, t_trip + 4);
+#pragma unroll 1   // one step per loop body: unrolled, n >= 6 would leave the 256 architectural registers
+        for (int32_t t = t_trip; t < t_end; ++t) {
         // policy + physics of one step (swimmer_row.h); the other segments' angles and angular
         // velocities are read straight out of their lanes by fused broadcast-FMAs
-        const double rq = sw::row_step<N>(C, L, V, nbias, K, magic, gdx, gdy, A, th, thd, thmax);
+        const double rq = sw::row_step<N>(C, L, V, nbias, cosine, gdx, gdy, A, th, thd);
         asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
         // the return comes out of the per-component sums in the epilogue (linearity)
         sgx += gdx;
@@ -1373,9 +1382,10 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             qgx = __builtin_fma(gdx, gdx, qgx);
             qgy = __builtin_fma(gdy, gdy, qgy);
         }
+        }
     }
 
-    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
+    thmax = fmax(thmax, fabs(th));
     // ---- per-rollout outputs ----
     {
         double bad[N], big[N], piv[N];

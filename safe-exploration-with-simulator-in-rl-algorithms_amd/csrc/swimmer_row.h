@@ -20,14 +20,16 @@
 //   The joint torques never exist as such: lane i needs only u_{i-1} - u_i, which is linear in
 //   the observation, so it holds the pre-combined policy row V_i = c12 (W_{i-1} - W_i) and
 //   evaluates one 2n+2-term dot product on the state (the mean enters as one constant).
-//   Lanes N..15 of a row mirror lane 0 and are never read; their stores are dropped by the
-//   buffer range check.
+//   Lane i + 8 of a row mirrors lane i (it evaluates the cosine of that segment's angle, see
+//   row_step); lanes N..7 and N + 8..15 mirror lane 0 / 8.  Mirrors are never read by a broadcast;
+//   their stores are dropped by the buffer range check.
 //
 // Per step for n = 6: ~250 instructions per lane instead of ~1050 in rollout_kernel<6>.
 // Equations and notation: swimmer_device.h.
 #pragma once
 
 #include "swimmer_device.h"
+#include "swimmer_oct3.h"
 #include "swimmer_row_fused.h"
 
 namespace sw {
@@ -116,17 +118,36 @@ struct RowEliminate {
 // One explicit-Euler step.  gdx, gdy: replicated (bit-identical on all lanes); th, thd: own
 // segment; V: this lane's pre-combined policy row, nbias = -V . mean.  Returns this lane's
 // reciprocal pivot (positive for a positive definite system).
-// The angle is carried in reduced form (Angle, swimmer_device.h): A is authoritative, th =
-// fl(K pi/2 + r) is what the policy, the trajectory and the statistics see; thmax collects
-// |theta| whenever an angle is re-normalised (SW_STATUS_RANGE).
+// sin / cos with LANE ROLES (round 3, as in swimmer_oct3.h): lane i < 8 of the row evaluates the
+// SINE of segment i's reduced angle, lane i + 8 -- a full mirror of lane i, same segment, same
+// state bit for bit -- the COSINE, with one Horner chain whose coefficients are per-lane state
+// (OctTrig: the quarter turns are folded into which polynomial a lane evaluates and its sign);
+// `v_mov_b32_dpp row_ror:8` hands each lane its partner's value and a per-lane select puts both in
+// canonical (s, c) order, so both halves go on with identical numbers: 10 + 2 + 4 instructions
+// instead of 20 (two polynomials + rotation).  T is authoritative for the angle, th = fl(K pi/2 +
+// r) is what the policy, the trajectory and the statistics see; the caller checks the range once
+// per trip of four steps (oct3_renorm).
 template <int N>
 __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
                                            const double (&V)[2 * N + 2], double nbias,
-                                           const TrigK &K, double magic, double &gdx, double &gdy,
-                                           Angle &A, double &th, double &thd, double &thmax)
+                                           bool cosine, double &gdx, double &gdy,
+                                           OctTrig &T, double &th, double &thd)
 {
     double s, c;
-    sincos_angle(A, s, c, K);
+    {
+        const double r = T.r, z = r * r;
+        double p = fma3(T.k[0], z, T.k[1]);
+        p = fma3(p, z, T.k[2]);
+        p = fma3(p, z, T.k[3]);
+        p = fma3(p, z, T.k[4]);
+        p = fma3(p, z, T.k[5]);
+        p = fma3(p, z, T.k[6]);
+        const double X = __builtin_fma(T.selS, r, T.selC);
+        const double own = __builtin_fma(X * z, p, X);        // sin theta on lanes 0..7, cos theta on 8..15
+        const double other = dpp_row_f64<kDppRowRor8>(own);
+        s = cosine ? other : own;
+        c = cosine ? own : other;
+    }
     double sk[N], ck[N];
     RowGather<N>::run(s, sk);
     RowGather<N>::run(c, ck);
@@ -152,9 +173,8 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
     RowFused<N>::velocity(g, r, thd, sq, vc, tc);
     double sx = 0.0, sy = 0.0;
     RowFused<N>::sums(sx, sy, r, g, sk, ck, ac);
-    A.r = __builtin_fma(C.h, thd, A.r);               // explicit Euler: the OLD thetadot
-    angle_keep_reduced(A, thmax, magic);              // compare + untaken branch
-    th = angle_theta(A);
+    T.r = __builtin_fma(C.h, thd, T.r);               // explicit Euler: the OLD thetadot
+    th = __builtin_fma(T.kd, kPio2Hi, T.r);
     // everything the elimination reads by DPP is written before the first pivot is broadcast
     RowFused<N>::fence(a);
     RowEliminate<N>::run(L, a, r);
