@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -1151,7 +1152,13 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
     Th = __builtin_fma(V[6], sw::dpp_f64<sw::kDppNext2>(th), Th);
     const double hV2 = C.h * V[2], hV4 = C.h * V[4], hV6 = C.h * V[6];
     sw::OctGeo G = sw::oct3_geometry(A), Gn;
+    double magic = 6755399441055744.0;   // 1.5 * 2^52, pinned in a VGPR pair for oct3_keep_reduced
+    asm volatile("" : "+v"(magic));
     auto one_step = [&](const sw::OctGeo &Gc, sw::OctGeo &Gx) {
+        // theta_{t+1} needs thetadot_t only: advance the angle first and start its range test, the
+        // policy's eight FMAs sit between the vector compare and the scalar branch that waits for it
+        A.r = __builtin_fma(C.h, thd, A.r);
+        const unsigned long long outside = sw::oct3_range_test(A.r);
         double tq = __builtin_fma(VPu, Pu, Th);
         tq = __builtin_fma(VPv, Pv, tq);
         tq = __builtin_fma(V[3], thd, tq);
@@ -1160,7 +1167,7 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
         Th = __builtin_fma(hV2, thd, Th);
         Th = __builtin_fma(hV4, w1, Th);
         Th = __builtin_fma(hV6, w2, Th);
-        A.r = __builtin_fma(C.h, thd, A.r);
+        sw::oct3_keep_reduced(A, thmax, magic, designation, outside);   // untaken branch; rare re-normalisation
         const double th_next = __builtin_fma(A.kd, sw::kPio2Hi, A.r);
         Gx = sw::oct3_geometry(A);
         det = sw::oct3_dynamics(C, O, Gc, Pu, Pv, thd, w1, w2, tq);
@@ -1184,31 +1191,19 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
         w2 = sw::dpp_f64<sw::kDppNext2>(thd);
         Pv = sw::dpp_row_f64<sw::kDppRowRor8>(Pu);
     };
-    // Range check ONCE PER TRIP: will |r| stay inside [-pi/4, pi/4] for the next `steps` steps at the
-    // present angular velocity?  If any lane says no, all lanes re-normalise (no-op where |r| <= pi/4).
-    // What thetadot gains within a trip may carry r a little past pi/4: the polynomials are accurate
-    // to 1.4e-16 up to pi/4 + 0.03 (swimmer_oct3.h).
-    auto keep_reduced = [&](int steps) {
-        const double reach = __builtin_fma((double)steps * C.h, fabs(thd), fabs(A.r));
-        if (__builtin_expect(__any(reach > sw::kPio4), 0)) sw::oct3_renorm(A, designation, thmax);
-    };
+    // four steps per trip, the geometry ping-pongs between G and Gn (no register copies)
     int32_t t = 0;
     for (; t + 4 <= H; t += 4) {
-        keep_reduced(4);
         one_step(G, Gn);
         one_step(Gn, G);
         one_step(G, Gn);
         one_step(Gn, G);
     }
     for (; t + 2 <= H; t += 2) {
-        keep_reduced(2);
         one_step(G, Gn);
         one_step(Gn, G);
     }
-    if (t < H) {
-        keep_reduced(1);
-        one_step(G, Gn);
-    }
+    if (t < H) one_step(G, Gn);
     thmax = fmax(thmax, fabs(th));
     asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
 
@@ -1351,17 +1346,11 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     A.r = th;
     A.kd = 0.0;
     sw::oct3_renorm(A, designation, thmax);
-    for (int32_t t_trip = 0; t_trip < H; t_trip += 4) {
-        // range check once per trip of four steps (swimmer_oct3.h): will |r| stay inside
-        // [-pi/4, pi/4] at the present angular velocity?  If any lane says no, all re-normalise.
-        const double reach = __builtin_fma(4.0 * C.h, fabs(thd), fabs(A.r));
-        if (__builtin_expect(__any(reach > sw::kPio4), 0)) sw::oct3_renorm(A, designation, thmax);
-        const int32_t t_end = min(H, t_trip + 4);
-#pragma unroll 1   // one step per loop body: unrolled, n >= 6 would leave the 256 architectural registers
-        for (int32_t t = t_trip; t < t_end; ++t) {
-        // policy + physics of one step (swimmer_row.h); the other segments' angles and angular
-        // velocities are read straight out of their lanes by fused broadcast-FMAs
-        const double rq = sw::row_step<N>(C, L, V, nbias, cosine, gdx, gdy, A, th, thd);
+    // one step: policy + physics (swimmer_row.h; the other segments' angles and angular velocities are
+    // read straight out of their lanes by fused broadcast-FMAs), then the step's records
+    auto one_step = [&](auto slow) {
+        const double rq = sw::row_step<N, decltype(slow)::value>(C, L, V, nbias, cosine, designation, gdx, gdy,
+                                                                 A, th, thd, thmax);
         asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
         // the return comes out of the per-component sums in the epilogue (linearity)
         sgx += gdx;
@@ -1382,7 +1371,26 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             qgx = __builtin_fma(gdx, gdx, qgx);
             qgy = __builtin_fma(gdy, gdy, qgy);
         }
+    };
+    // Range check once per trip of four steps, as in the mirror-quad kernel (see there): a trip whose
+    // angles move at most kTripSlack runs unchecked after one re-normalisation at its start if needed;
+    // a faster trip checks inside every step.  One step per loop body either way: unrolled, n >= 6
+    // would leave the 256 architectural registers.
+    auto too_fast = [&]() -> bool {
+        return __any((4.0 * C.h) * fabs(thd) > sw::kTripSlack);
+    };
+    int32_t t = 0;
+    while (t < H) {                                  // two loops, not one loop with two bodies (see the oct kernel)
+        while (t < H) {                              // unchecked trips of (up to) four steps
+            if (__builtin_expect(too_fast(), 0)) break;
+            const double reach = __builtin_fma(4.0 * C.h, fabs(thd), fabs(A.r));
+            if (__builtin_expect(__any(reach > sw::kPio4), 0)) sw::oct3_renorm(A, designation, thmax);
+            const int32_t t_end = min(H, t + 4);
+#pragma unroll 1
+            for (; t < t_end; ++t) one_step(std::false_type{});
         }
+#pragma unroll 1
+        for (; t < H && too_fast(); ++t) one_step(std::true_type{});   // checks inside every step
     }
 
     thmax = fmax(thmax, fabs(th));

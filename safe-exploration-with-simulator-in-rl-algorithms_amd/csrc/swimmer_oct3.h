@@ -26,12 +26,15 @@
 // so a lane's DESIGNATED output (A: sin theta, B: cos theta) is one of the two polynomials of r with
 // a sign: the lane's coefficient set and the sign (in selS / selC) are state, re-chosen only when K
 // changes -- in the rare re-normalisation block, which is plain C++ here because it is entered from
-// a check made ONCE PER TRIP of four steps, not per step: |r| + 4 h |thetadot| > pi/4.  Between
-// two checks r may leave [-pi/4, pi/4] by what thetadot gains within a trip; the polynomials stay
-// accurate to 1.4e-16 up to pi/4 + 0.03 (1.2e-16 inside), checked against long-double libm.
+// a check made ONCE PER TRIP of four steps, not per step: |r| + 4 h |thetadot| > pi/4 (re-normalise now,
+// then run the trip unchecked).  During the trip r may leave [-pi/4, pi/4] by at most what the angle
+// travels in it, and a trip only runs unchecked if that is <= kTripSlack = 0.04 rad on every lane: the
+// polynomials stay accurate to 1.4e-16 up to pi/4 + 0.03 and 2.5e-16 up to pi/4 + 0.04 (1.2e-16 inside;
+// checked against long-double libm).  Trips with a faster lane (|thetadot| > 10 rad/s at h = 1e-3)
+// check inside every step, between the angle update and the evaluation: exact for ANY angular velocity.
 //
-// Per step: 10 instructions of sin/cos + 2 moves instead of 20 + 4 of rotation + 2 of range check,
-// one barycentre sum instead of two, no per-lane select for the recorded Gdot component
+// Per step: 10 instructions of sin/cos + 2 moves instead of 20 + 4 of rotation, one barycentre sum
+// instead of two, no per-lane select for the recorded Gdot component
 // (scripts/isa_loop_stats.py).  The rollout's trajectory is quad A's copy of (theta, thetadot,
 // Gdot_x) and quad B's Gdot_y.
 //
@@ -43,6 +46,11 @@
 #include "swimmer_quad3.h"
 
 namespace sw {
+
+// Row kernel (swimmer_row.h): what an angle may move during an unchecked trip of four steps -- the
+// polynomials are evaluated at most this far (plus what thetadot gains within the trip) outside
+// [-pi/4, pi/4], where they are accurate to 2.5e-16.  Trips with a faster lane check inside every step.
+constexpr double kTripSlack = 0.04;
 
 constexpr int kDppRowRor8 = 0x128;   // dpp_ctrl row_ror:8 -- lane L of a 16-lane row reads lane (L + 8) % 16
 
@@ -107,6 +115,84 @@ __device__ __forceinline__ void oct3_renorm(OctTrig &T, int designation, double 
     T.kd += k;
     oct3_retype(T, designation);
     thmax = fmax(thmax, fabs(__builtin_fma(T.kd, kPio2Hi, T.r)));
+}
+
+// The per-step form of oct3_renorm for the hot loop: ONE compare and ONE (normally not taken) scalar
+// branch; the re-normalisation AND the re-choice of the polynomial behind it work in place on T and
+// thmax, out of line (end of the function's section: the common path falls through an untaken branch;
+// written as asm because the compiler lays the same C++ out with the rare path inline and register
+// copies on the common one -- measured +12 % on the launch).  No lane predication: lanes inside
+// [-pi/4, pi/4] move k = 0 quarter turns and re-choose what they had.  The coefficient sets come in
+// as scalar registers; a lane's set is type * C_j + (1 - type) * S_j with type in {0, 1}: exact.
+// Checked after every angle update, before the polynomial is evaluated: exact for ANY angular velocity.
+// The compare and the branch are two statements (oct3_range_test / oct3_keep_reduced) with the lane
+// mask in a scalar register pair between them, so that the caller can put independent work between
+// the vector compare and the scalar branch that waits for its result (back to back the pair cost
+// ~2.7 % of the launch beyond its two issue slots).
+__device__ __forceinline__ unsigned long long oct3_range_test(double r)
+{
+    unsigned long long mask;
+    asm volatile("v_cmp_gt_f64_e64 %[m], |%[r]|, %[lim]" : [m] "=s"(mask) : [r] "v"(r), [lim] "s"(kPio4));
+    return mask;
+}
+
+__device__ __forceinline__ void oct3_keep_reduced(OctTrig &T, double &thmax, double magic, int designation,
+                                                  unsigned long long outside)
+{
+    double t0, t1, t2;
+    int q, q1;
+    asm volatile(
+        "s_cmp_lg_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 .Lsw_oct_renorm_%=\n"
+        ".Lsw_oct_reduced_%=:\n\t"
+        ".subsection 1\n"
+        ".Lsw_oct_renorm_%=:\n\t"
+        "v_fma_f64 %[t1], %[r], %[c2opi], %[magic]\n\t"     // k + magic
+        "v_add_f64 %[t0], %[t1], -%[magic]\n\t"             // k = rint(r * 2/pi)
+        "v_fma_f64 %[r], -%[t0], %[hi], %[r]\n\t"           // exact
+        "v_fma_f64 %[r], -%[t0], %[lo], %[r]\n\t"
+        "v_add_f64 %[kd], %[kd], %[t0]\n\t"
+        "v_cvt_i32_f64_e32 %[q], %[kd]\n\t"                 // K (|K| < 2^31 inside the valid range)
+        "v_add_u32_e32 %[q], %[q], %[des]\n\t"              // cos(theta) = sin(theta + pi/2): K + 1
+        "v_and_b32_e32 %[q1], 1, %[q]\n\t"                  // type: 1 = cosine polynomial
+        "v_and_b32_e32 %[q], 2, %[q]\n\t"
+        "v_cvt_f64_i32_e32 %[t0], %[q]\n\t"                 // 0 or 2
+        "v_add_f64 %[t0], 1.0, -%[t0]\n\t"                  // sign
+        "v_cvt_f64_i32_e32 %[t1], %[q1]\n\t"                // type as 0.0 / 1.0
+        "v_mul_f64 %[selC], %[t1], %[t0]\n\t"               // type * sign
+        "v_add_f64 %[selS], %[t0], -%[selC]\n\t"            // (1 - type) * sign
+        "v_add_f64 %[t0], 1.0, -%[t1]\n\t"                  // 1 - type
+        "v_mul_f64 %[t2], %[t0], %[s0]\n\t"
+        "v_fma_f64 %[k0], %[t1], %[c0], %[t2]\n\t"
+        "v_mul_f64 %[t2], %[t0], %[s1]\n\t"
+        "v_fma_f64 %[k1], %[t1], %[c1], %[t2]\n\t"
+        "v_mul_f64 %[t2], %[t0], %[s2]\n\t"
+        "v_fma_f64 %[k2], %[t1], %[c2], %[t2]\n\t"
+        "v_mul_f64 %[t2], %[t0], %[s3]\n\t"
+        "v_fma_f64 %[k3], %[t1], %[c3], %[t2]\n\t"
+        "v_mul_f64 %[t2], %[t0], %[s4]\n\t"
+        "v_fma_f64 %[k4], %[t1], %[c4], %[t2]\n\t"
+        "v_mul_f64 %[t2], %[t0], %[s5]\n\t"
+        "v_fma_f64 %[k5], %[t1], %[c5], %[t2]\n\t"
+        "v_mul_f64 %[t2], %[t0], %[s6]\n\t"
+        "v_fma_f64 %[k6], %[t1], %[c6], %[t2]\n\t"
+        "v_fma_f64 %[t0], %[kd], %[hi], %[r]\n\t"
+        "v_max_f64 %[thmax], %[thmax], |%[t0]|\n\t"
+        "s_branch .Lsw_oct_reduced_%=\n\t"
+        ".subsection 0"
+        : [r] "+v"(T.r), [kd] "+v"(T.kd), [selS] "+v"(T.selS), [selC] "+v"(T.selC), [thmax] "+v"(thmax),
+          [k0] "+v"(T.k[0]), [k1] "+v"(T.k[1]), [k2] "+v"(T.k[2]), [k3] "+v"(T.k[3]), [k4] "+v"(T.k[4]),
+          [k5] "+v"(T.k[5]), [k6] "+v"(T.k[6]),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [q] "=&v"(q), [q1] "=&v"(q1)
+        : [lim] "s"(kPio4), [c2opi] "s"(0.63661977236758134308), [hi] "s"(kPio2Hi), [lo] "s"(kPio2Lo),
+          [magic] "v"(magic), [des] "v"(designation), [m] "s"(outside),
+          [s0] "s"(0.0), [s1] "s"(1.58969099521155010221e-10), [s2] "s"(-2.50507602534068634195e-08),
+          [s3] "s"(2.75573137070700676789e-06), [s4] "s"(-1.98412698298579493134e-04),
+          [s5] "s"(8.33333333332248946124e-03), [s6] "s"(-1.66666666666666324348e-01),
+          [c0] "s"(-1.13596475577881948265e-11), [c1] "s"(2.08757232129817482790e-09),
+          [c2] "s"(-2.75573143513906633035e-07), [c3] "s"(2.48015872894767294178e-05),
+          [c4] "s"(-1.38888888888741095749e-03), [c5] "s"(4.16666666666666019037e-02), [c6] "s"(-0.5)
+        : "scc");
 }
 
 __device__ __forceinline__ OctLane oct3_lane(const Consts &C, int seg, bool cosine)

@@ -126,12 +126,14 @@ struct RowEliminate {
 // canonical (s, c) order, so both halves go on with identical numbers: 10 + 2 + 4 instructions
 // instead of 20 (two polynomials + rotation).  T is authoritative for the angle, th = fl(K pi/2 +
 // r) is what the policy, the trajectory and the statistics see; the caller checks the range once
-// per trip of four steps (oct3_renorm).
-template <int N>
+// per trip of four steps (oct3_renorm), or -- SLOW -- this function does after the angle update.
+// SLOW: re-normalise inside the step, between the angle update and the next step's sin / cos
+// (trips during which an angle moves more than kTripSlack, see the kernel).
+template <int N, bool SLOW>
 __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
                                            const double (&V)[2 * N + 2], double nbias,
-                                           bool cosine, double &gdx, double &gdy,
-                                           OctTrig &T, double &th, double &thd)
+                                           bool cosine, int designation, double &gdx, double &gdy,
+                                           OctTrig &T, double &th, double &thd, double &thmax)
 {
     double s, c;
     {
@@ -174,6 +176,9 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
     double sx = 0.0, sy = 0.0;
     RowFused<N>::sums(sx, sy, r, g, sk, ck, ac);
     T.r = __builtin_fma(C.h, thd, T.r);               // explicit Euler: the OLD thetadot
+    if constexpr (SLOW) {
+        if (__any(fabs(T.r) > kPio4)) oct3_renorm(T, designation, thmax);
+    }
     th = __builtin_fma(T.kd, kPio2Hi, T.r);
     // everything the elimination reads by DPP is written before the first pivot is broadcast
     RowFused<N>::fence(a);

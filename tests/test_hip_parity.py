@@ -334,6 +334,40 @@ def test_covariance_pass_on_ragged_tiles(sw, n, R, H):
     assert np.array_equal(acc, sw.kernels.traj_moments(p, traj)[:1 + d + d * d].cpu().numpy())
 
 
+@pytest.mark.parametrize("n", [3, 6])
+@pytest.mark.parametrize("kernel", ["lane", "quad"])
+def test_fast_spinning_segments_stay_exact(sw, n, kernel):
+    """Start states with angular velocities of up to 400 rad/s (0.4 rad per step: a segment crosses
+    a quadrant boundary every few steps) and angles of up to 50 rad.  The segment-per-lane kernels
+    carry reduced angles; their range checks (every step in the n = 3 kernels; per trip of four steps
+    in the row kernel, switching to every step when an angle travels more than 0.04 rad in a trip) must
+    keep sin / cos exact for any angular velocity: same agreement with the oracle as the lane kernel."""
+    rs = np.random.RandomState(7 + n)
+    R, H, d, m = 48, 120, 2 * n + 2, n - 1
+    st0 = np.empty((R, d))
+    st0[:, 0:2] = rs.uniform(-0.5, 0.5, (R, 2))
+    st0[:, 2::2] = rs.uniform(-50.0, 50.0, (R, n))
+    # n = 3 takes 400 rad/s; the 6-segment chain's explicit Euler step blows up there (in the reference
+    # too), 60 rad/s = 0.06 rad per step is still six times what an unchecked trip allows
+    top = 400.0 if n == 3 else 60.0
+    st0[:, 3::2] = rs.uniform(-top, top, (R, n))
+    st0[: R // 2, 3::2] *= 0.05          # half of the batch twenty times slower: slow and fast trips mixed in one wave
+    pol = 0.05 * (2 * rs.rand(R, m, d) - 1)
+    op = oracle.OracleParams.make(n)
+    ref = np.stack([oracle.rollout(op, H, pol[r], state0=st0[r])[1] for r in range(R)])      # [R, H, d]
+    p = sw.SwParams.make(n, flags=sw._lib.kernel_flags(kernel))
+    traj = torch.empty((H, d, R), dtype=torch.float64, device="cuda:0")
+    status = torch.zeros(R, dtype=torch.int32, device="cuda:0")
+    sw.kernels.rollout(p, H, torch.as_tensor(pol, device="cuda:0"), state0=soa(st0), traj=traj, status=status)
+    got = traj.permute(2, 0, 1).cpu().numpy()
+    assert int(status.abs().sum()) == 0
+    # violent states (|thetadot| of hundreds, friction forces to match): the lane kernel itself is 4e-8
+    # (relative) from the oracle after 120 such steps; a sin / cos evaluated one step's travel
+    # outside its range would be off by 1e-3 and more
+    scale = np.maximum(1.0, np.abs(ref))
+    assert (np.abs(got - ref) / scale).max() <= 1e-6           # contract: 1e-5
+
+
 def test_edge_cases(sw):
     p = sw.SwParams.make(3)
     dev = "cuda:0"
