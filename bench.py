@@ -44,7 +44,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 # Instructions one wave issues per env-step in the segment-per-lane rollout kernels: ISA count of
 # the hot loop incl. trajectory stores + moments (scripts/isa_loop_stats.py, the out-of-line
 # re-normalisation blocks not counted): (f64 VALU, everything else).  Round 1: 145 / 256 in all.
-ROLLOUT_INSTR_PER_STEP = {3: (81, 32), 6: (202, 39)}   # n = 3: the mirror-quad kernel (round 2's quad kernel: 98 + 26)
+ROLLOUT_INSTR_PER_STEP = {3: (81, 32), 6: (201, 38)}   # n = 3: the mirror-quad kernel (round 2's quad kernel: 98 + 26)
 # Measured issue interval of a lone wave (profiles/r01_ubench_issue_cost.log): an independent f64
 # FMA / multiply 2.12 ns, a 32-bit move / DPP move / SALU 1.92-2.03 ns: what actually bounds the
 # latency-bound rollout (boxes differ by ~2 % in clock, so the fraction can come out just above 1).

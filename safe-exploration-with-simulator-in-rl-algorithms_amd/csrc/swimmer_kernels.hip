@@ -1269,8 +1269,12 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
 // ------------------------------------------------------------------------------------
 // n = 4..8, one segment per lane, one rollout per 16-lane DPP row (swimmer_row.h).
 // 256-thread workgroups: 4 waves x 4 rows = 16 rollouts = one V2 moment row.
+// Two waves per SIMD must fit for n <= 6 (256 registers each): the covariance workgroups that ride along
+// are waves of THIS kernel, and once a batch puts a rollout wave on every SIMD (2048 directions on one
+// GPU) a wave that needs more than half the register file cannot join it -- the pass would run after the
+// rollouts (measured at 264 registers: launch 0.69 -> 0.89 ms, profiles/r03_h_ab_row_registers.log).
 template <int N, bool ARS, bool TRAJ, bool MOM>
-__global__ void __launch_bounds__(kRowBlock)
+__global__ void __launch_bounds__(kRowBlock, (N <= 6 ? 2 : 1))
 rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__restrict__ policies,
                    const double *__restrict__ deltas, int64_t dir_begin, double nu,
                    const double *__restrict__ mean, const double *__restrict__ inv_std,
@@ -1337,7 +1341,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
     };
 
-    double thmax = 0.0, pivmin_all = 1.0;
+    double thmax = 0.0, rq_last = 1.0;
     double m1th = 0.0, m2th = 0.0, m1thd = 0.0, m2thd = 0.0;
     double sgx = 0.0, sgy = 0.0, qgx = 0.0, qgy = 0.0;   // sums of Gdot and Gdot^2 over the steps
     // theta = r + K pi/2 and the polynomial this lane evaluates of r (swimmer_oct3.h, OctTrig)
@@ -1351,7 +1355,8 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     auto one_step = [&](auto slow) {
         const double rq = sw::row_step<N, decltype(slow)::value>(C, L, V, nbias, cosine, designation, gdx, gdy,
                                                                  A, th, thd, thmax);
-        asm("v_min_f64 %0, %1, %2" : "=v"(pivmin_all) : "v"(pivmin_all), "v"(rq));
+        rq_last = rq;   // the system is the chain's mass matrix: a pivot can only fail to be positive once the
+                        // state is no longer finite, and then the last step's says so
         // the return comes out of the per-component sums in the epilogue (linearity)
         sgx += gdx;
         sgy += gdy;
@@ -1400,7 +1405,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         const bool fin = isfinite(th) && isfinite(thd) && isfinite(gdx) && isfinite(gdy);
         sw::RowGather<N>::run(fin ? 0.0 : 1.0, bad);
         sw::RowGather<N>::run(thmax, big);
-        sw::RowGather<N>::run(pivmin_all, piv);   // every segment lane's smallest 1 / pivot
+        sw::RowGather<N>::run(rq_last, piv);      // every segment lane's last 1 / pivot
         double nbad = 0.0, tmax = 0.0, pmin = 1.0;
 #pragma unroll
         for (int k = 0; k < N; ++k) {

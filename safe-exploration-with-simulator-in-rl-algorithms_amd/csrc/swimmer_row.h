@@ -47,8 +47,9 @@ template <int N>
 struct RowLane {
     double vwl[N];     // l * vel_w(i,k)
     double af[N];      // -(6k/m) * Aw(i,k)
-    double t6[N];      // -6 T(i,k), 0 for k = i
-    double od[N];      // diagonal of Q at k = i (-6 T(i,i) + 1), 0 elsewhere
+    double t6[N];      // row i of Q as a factor of cos(th_i - th_k): -6 T(i,k), and the diagonal -6 T(i,i) + 1 at
+                       // k = i (there cos(0) comes out as c^2 + s^2 = 1 to an ulp and sin(0) as a product's rounding
+                       // residue ~1e-17: the centripetal weight t6[i] * ss stays at rounding level)
     double one[N];     // 1 at k = i
     double nbelow[N];  // -1 where i > k   (elimination step k updates this lane)
     double nabove[N];  // -1 where i < k   (back-substitution level k updates this lane)
@@ -60,19 +61,17 @@ __device__ __forceinline__ RowLane<N> row_lane(const Consts &C, int seg)
     RowLane<N> L;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        double vw = 0.0, a = 0.0, t = 0.0, od = 0.0;
+        double vw = 0.0, a = 0.0, t = 0.0;
 #pragma unroll
         for (int ii = 0; ii < N; ++ii)
             if (seg == ii) {
                 vw = vel_w<N>(ii + 1, k + 1);
                 a = Aw<N>(ii + 1, k + 1);
-                t = (ii == k) ? 0.0 : -6.0 * Tw<N>(ii + 1, k + 1);
-                od = (ii == k) ? -6.0 * Tw<N>(ii + 1, ii + 1) + 1.0 : 0.0;
+                t = (ii == k) ? -6.0 * Tw<N>(ii + 1, ii + 1) + 1.0 : -6.0 * Tw<N>(ii + 1, k + 1);
             }
         L.vwl[k] = vw * C.l;
         L.af[k] = -C.six_k_m * a;
         L.t6[k] = t;
-        L.od[k] = od;
         L.one[k] = (seg == k) ? 1.0 : 0.0;
         L.nbelow[k] = (seg > k) ? -1.0 : 0.0;
         L.nabove[k] = (seg < k) ? -1.0 : 0.0;
@@ -166,7 +165,7 @@ __device__ __forceinline__ double row_step(const Consts &C, const RowLane<N> &L,
         vc[k] = L.vwl[k] * cc;                        // normal-velocity weights
         ac[k] = L.af[k] * cc;                         // friction weights of the right-hand side
         tc[k] = L.t6[k] * ss;                         // centripetal weights
-        a[k] = __builtin_fma(L.t6[k], cc, L.od[k]);   // own row of Q
+        a[k] = L.t6[k] * cc;                          // own row of Q
     }
     // g: normal velocity of this segment's centre;  r: right-hand side of this segment's row
     double g = __builtin_fma(gdy, c, -gdx * s);
