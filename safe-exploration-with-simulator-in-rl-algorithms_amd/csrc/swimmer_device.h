@@ -184,29 +184,36 @@ __device__ __forceinline__ void angle_renorm(Angle &A)
     A.sb = sb;
 }
 
-// The per-step form of angle_renorm for the hot loops: ONE compare and ONE (normally not taken)
-// scalar branch; the re-normalisation behind it works IN PLACE on A and thmax.  Written as an asm
+// The per-step form of angle_renorm for the quad kernel's hot loop: a vector compare, a scalar compare
+// and ONE (normally not taken) scalar branch; the re-normalisation behind it works IN PLACE on A and thmax.  Written as an asm
 // block because the compiler lays the same C++ out with the rare path as the fall-through and
 // five register copies on the common one.  No lane predication: lanes inside [-pi/4, pi/4] move
 // k = 0 quarter turns.  thmax <- max(thmax, |theta|) on that path: every way to a huge angle
 // leads through it (|theta| moves less than pi/2 between two re-normalisations).
 // magic = 1.5 * 2^52 in a VGPR pair (VOP3 takes one scalar operand on gfx9).
-__device__ __forceinline__ void angle_keep_reduced(Angle &A, double &thmax, double magic)
+// Compare and branch are TWO statements (angle_range_test / angle_keep_reduced) with the lane mask in a
+// scalar register pair between them: the caller puts independent work between the vector compare and
+// the scalar branch that waits for its result (back to back the pair costs ~3 % of a rollout launch
+// beyond its issue slots, profiles/r03_g_ab_range_check_variants.log).
+__device__ __forceinline__ unsigned long long angle_range_test(double r)
+{
+    unsigned long long mask;
+    asm volatile("v_cmp_gt_f64_e64 %[m], |%[r]|, %[lim]" : [m] "=s"(mask) : [r] "v"(r), [lim] "s"(kPio4));
+    return mask;
+}
+
+__device__ __forceinline__ void angle_keep_reduced(Angle &A, double &thmax, double magic, unsigned long long outside)
 {
     double t0, t1, p, w;
     int q, q1;
     asm volatile(
-        "v_cmp_gt_f64_e64 vcc, |%[r]|, %[lim]\n\t"
-#ifdef SW_RENORM_INLINE
-        "s_cbranch_vccz .Lsw_reduced_%=\n\t"
-#else
+        "s_cmp_lg_u64 %[m], 0\n\t"
         // the rare path lives out of line (end of this function's section): the common path
         // falls through an UNTAKEN branch
-        "s_cbranch_vccnz .Lsw_renorm_%=\n"
+        "s_cbranch_scc1 .Lsw_renorm_%=\n"
         ".Lsw_reduced_%=:\n\t"
         ".subsection 1\n"
         ".Lsw_renorm_%=:\n\t"
-#endif
         "v_fma_f64 %[t1], %[r], %[c2opi], %[magic]\n\t"     // k + magic
         "v_add_f64 %[t0], %[t1], -%[magic]\n\t"             // k = rint(r * 2/pi)
         "v_fma_f64 %[r], -%[t0], %[hi], %[r]\n\t"           // exact
@@ -226,63 +233,14 @@ __device__ __forceinline__ void angle_keep_reduced(Angle &A, double &thmax, doub
         "v_fma_f64 %[sa], -%[t1], %[w], %[sa]\n\t"          // odd: (sa, sb) <- (-sb u, sa u)
         "v_fma_f64 %[sb], %[t1], %[p], %[sb]\n\t"
         "v_fma_f64 %[t0], %[kd], %[hi], %[r]\n\t"
-#ifdef SW_RENORM_INLINE
-        "v_max_f64 %[thmax], %[thmax], |%[t0]|\n"
-        ".Lsw_reduced_%=:"
-#else
-        "v_max_f64 %[thmax], %[thmax], |%[t0]|\n\t"
-        "s_branch .Lsw_reduced_%=\n\t"
-        ".subsection 0"
-#endif
-        : [r] "+v"(A.r), [kd] "+v"(A.kd), [sa] "+v"(A.sa), [sb] "+v"(A.sb), [thmax] "+v"(thmax),
-          [t0] "=&v"(t0), [t1] "=&v"(t1), [p] "=&v"(p), [w] "=&v"(w), [q] "=&v"(q), [q1] "=&v"(q1)
-        : [lim] "s"(kPio4), [c2opi] "s"(0.63661977236758134308), [hi] "s"(kPio2Hi),
-          [lo] "s"(kPio2Lo), [magic] "v"(magic)
-        : "vcc");
-}
-
-// angle_keep_reduced for lanes that keep sb SIGNED by a per-lane role sign sigma = +-1
-// (swimmer_oct3.h: A.sb holds sigma sin(K pi/2)): the quarter-turn rotation of (sa, sigma sb) by k
-// turns is the rotation by sigma k, i.e. the odd-k terms take the factor sigma.  One more multiply
-// on the rare path, the hot path (compare + untaken branch) is the same.
-__device__ __forceinline__ void angle_keep_reduced_signed(Angle &A, double &thmax, double magic, double sigma)
-{
-    double t0, t1, p, w;
-    int q, q1;
-    asm volatile(
-        "v_cmp_gt_f64_e64 vcc, |%[r]|, %[lim]\n\t"
-        "s_cbranch_vccnz .Lsw_renorm_%=\n"
-        ".Lsw_reduced_%=:\n\t"
-        ".subsection 1\n"
-        ".Lsw_renorm_%=:\n\t"
-        "v_fma_f64 %[t1], %[r], %[c2opi], %[magic]\n\t"     // k + magic
-        "v_add_f64 %[t0], %[t1], -%[magic]\n\t"             // k = rint(r * 2/pi)
-        "v_fma_f64 %[r], -%[t0], %[hi], %[r]\n\t"           // exact
-        "v_fma_f64 %[r], -%[t0], %[lo], %[r]\n\t"
-        "v_add_f64 %[kd], %[kd], %[t0]\n\t"
-        "v_cvt_i32_f64_e32 %[q], %[t0]\n\t"
-        "v_and_b32_e32 %[q1], 1, %[q]\n\t"
-        "v_and_b32_e32 %[q], 2, %[q]\n\t"
-        "v_cvt_f64_i32_e32 %[t0], %[q]\n\t"                 // 0 or 2
-        "v_add_f64 %[t0], 1.0, -%[t0]\n\t"                  // u = cos / sin of the even part
-        "v_cvt_f64_i32_e32 %[t1], %[q1]\n\t"                // odd: 0 or 1
-        "v_mul_f64 %[p], %[sa], %[t0]\n\t"
-        "v_mul_f64 %[w], %[sb], %[t0]\n\t"
-        "v_add_f64 %[t0], 1.0, -%[t1]\n\t"                  // even: 1 or 0
-        "v_mul_f64 %[t1], %[t1], %[sig]\n\t"                // odd, signed by the lane's role
-        "v_mul_f64 %[sa], %[t0], %[p]\n\t"
-        "v_mul_f64 %[sb], %[t0], %[w]\n\t"
-        "v_fma_f64 %[sa], -%[t1], %[w], %[sa]\n\t"          // odd: (sa, sb~) <- (-sigma sb~ u, sigma sa u)
-        "v_fma_f64 %[sb], %[t1], %[p], %[sb]\n\t"
-        "v_fma_f64 %[t0], %[kd], %[hi], %[r]\n\t"
         "v_max_f64 %[thmax], %[thmax], |%[t0]|\n\t"
         "s_branch .Lsw_reduced_%=\n\t"
         ".subsection 0"
         : [r] "+v"(A.r), [kd] "+v"(A.kd), [sa] "+v"(A.sa), [sb] "+v"(A.sb), [thmax] "+v"(thmax),
           [t0] "=&v"(t0), [t1] "=&v"(t1), [p] "=&v"(p), [w] "=&v"(w), [q] "=&v"(q), [q1] "=&v"(q1)
-        : [lim] "s"(kPio4), [c2opi] "s"(0.63661977236758134308), [hi] "s"(kPio2Hi),
-          [lo] "s"(kPio2Lo), [magic] "v"(magic), [sig] "v"(sigma)
-        : "vcc");
+        : [c2opi] "s"(0.63661977236758134308), [hi] "s"(kPio2Hi),
+          [lo] "s"(kPio2Lo), [magic] "v"(magic), [m] "s"(outside)
+        : "scc");
 }
 
 __device__ __forceinline__ Angle angle_make(double theta)

@@ -969,6 +969,12 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         // this segment's torque balance c12 (u_{i-1} - u_i) = V_i . (obs - mean): the carried
         // angle part + the velocity part (the neighbours' angular velocities arrive by DPP and are
         // reused by the physics step).  One accumulator: the kernel is issue-bound, not chain-bound.
+        // theta_{t+1} needs thetadot_t only: advance the angle first and start its range test; the
+        // policy's eight FMAs sit between the vector compare and the scalar branch that waits for it.
+        // Its sin / cos and the neighbour exchange run beside this step's solve (software pipelining
+        // across steps, swimmer_quad3.h)
+        A.r = __builtin_fma(C.h, thd, A.r);
+        const unsigned long long outside = sw::angle_range_test(A.r);
         double tq = __builtin_fma(V[0], gdx, Th);
         tq = __builtin_fma(V[1], gdy, tq);
         tq = __builtin_fma(V[3], thd, tq);
@@ -977,10 +983,7 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
         Th = __builtin_fma(hV2, thd, Th);
         Th = __builtin_fma(hV4, w1, Th);
         Th = __builtin_fma(hV6, w2, Th);
-        // theta_{t+1} needs thetadot_t only: its sin / cos and the neighbour exchange run
-        // beside this step's solve (software pipelining across steps, swimmer_quad3.h)
-        A.r = __builtin_fma(C.h, thd, A.r);
-        sw::angle_keep_reduced(A, thmax, magic);   // compare + untaken branch; rare re-normalisation
+        sw::angle_keep_reduced(A, thmax, magic, outside);   // untaken branch; rare re-normalisation
         const double th_next = sw::angle_theta(A);
         Gx = sw::quad3_geometry(A, K);
         det = sw::quad3_dynamics(C, L, Gc, gdx, gdy, thd, w1, w2, tq);

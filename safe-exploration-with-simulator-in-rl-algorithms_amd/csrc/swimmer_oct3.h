@@ -71,7 +71,6 @@ struct OctLane {
     double kt1, kt2;           // sigma (-6 T(i, i1)), sigma (-6 T(i, i2))
     double t1, t2, t12;        // unsigned: the matrix entries
     double d0, d12, d1, d2;
-    double sigma;
 };
 
 // What a lane evaluates of its reduced angle: X (1 + z p(z)), z = r^2, X = selS r + selC.
@@ -215,7 +214,6 @@ __device__ __forceinline__ OctLane oct3_lane(const Consts &C, int seg, bool cosi
     O.d12 = L.d12;
     O.d1 = L.d1;
     O.d2 = L.d2;
-    O.sigma = sg;
     return O;
 }
 
