@@ -79,3 +79,52 @@ def test_ranks_match_single_process(N, world):
         assert (np.abs(cov - ref.covariance) <= 1e-9 * np.outer(sd, sd)).all()
     for other in res[1:]:
         assert np.array_equal(res[0][2], other[2])   # every rank holds the same policy
+
+
+def _ckpt_worker(rank, world, port, N, H, path, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import swimmer_amd as sw
+        a = _make_agent(sw, N, H, False, 5)
+        for _ in range(2):
+            a.runOneIteration()
+        a.save_checkpoint(path)                     # collective; rank 0 writes
+        dist.barrier()
+        tail_a = [a.runOneIteration() for _ in range(2)]
+        cov_a = a.reduce_covariance()
+        b = _make_agent(sw, N, H, False, 999)       # another seed: the checkpoint restores the stream
+        b.load_checkpoint(path)
+        tail_b = [b.runOneIteration() for _ in range(2)]
+        cov_b = b.reduce_covariance()
+        out.put((rank, np.array(tail_a), np.array(tail_b), a.policy, b.policy, cov_a, cov_b,
+                 b._cov_acc[:b._cov_sums].cpu().numpy(), a._cov_acc[:a._cov_sums].cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_checkpoint_resume_with_two_ranks_is_bit_exact(tmp_path):
+    """A checkpoint written by a two-rank run keeps EVERY rank's covariance sums (cov_acc_ranks): a
+    resume at the same world size restores them rank by rank, so returns, policy AND the full covariance
+    continue bit for bit (with the total on rank 0 only the covariance would differ by summation order)."""
+    N, H, world = 16, 100, 2
+    path = str(tmp_path / "ck2.npz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, world, port, N, H, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    z = np.load(path, allow_pickle=False)
+    assert z["cov_acc_ranks"].shape[0] == world
+    assert np.array_equal(z["cov_acc_ranks"].sum(0), z["cov_acc"])
+    for rank, tail_a, tail_b, pol_a, pol_b, cov_a, cov_b, acc_b, acc_a in res:
+        assert np.array_equal(tail_a, tail_b), rank
+        assert np.array_equal(pol_a, pol_b), rank
+        assert np.array_equal(acc_a, acc_b), rank          # this rank's own sums, bit for bit
+        assert np.array_equal(cov_a, cov_b), rank
