@@ -209,7 +209,9 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
 typedef struct sw_env1 sw_env1;
 int sw_env1_create(sw_env1 **out);
 void sw_env1_destroy(sw_env1 *e);
-/* HOST pointer to the handle's I/O block (SW_ENV1_DOUBLES doubles), valid until destroy. */
+/* A handle is used by one thread at a time (it owns one I/O block and one sequence counter) and
+ * belongs to the device that was current when it was created.
+ * HOST pointer to the handle's I/O block (SW_ENV1_DOUBLES doubles), valid until destroy. */
 double *sw_env1_io(sw_env1 *e);
 /* One physics step of the swimmer in the block (model chosen by p->flags); BLOCKING: the
  * outputs are in the block when it returns.  *status (host, may be NULL) receives SW_STATUS_*. */
@@ -227,6 +229,8 @@ int sw_env1_accel(sw_env1 *e, const sw_params *p);
  * Rank 0 draws the id, the caller distributes its SW_COMM_ID_BYTES bytes by whatever means it has
  * (torch.distributed broadcast, MPI, a file), every rank creates its communicator (collective). */
 #define SW_COMM_ID_BYTES 128
+/* sw_comm_create is COLLECTIVE over the ranks and binds the communicator to the CURRENT device
+ * (hipSetDevice first); one communicator per rank, one GPU per rank. */
 typedef struct sw_comm sw_comm;
 int sw_comm_available(void);
 int sw_comm_unique_id(uint8_t *id /* host, SW_COMM_ID_BYTES */);

@@ -5,8 +5,10 @@
 // 1024 SIMDs x 64 lanes.  With one rollout per lane (rollout_kernel) a batch of 1024
 // rollouts occupies 16 SIMDs and its speed is the length of one lane's instruction stream
 // (~310 instructions per step, one instruction per ~4.4 cycles for a lone wave,
-// scripts/ubench).  Spreading a rollout over the lanes of a quad cuts that stream to 124
-// instructions per step (round 1: 145) at 4x the (idle anyway) SIMD count:
+// scripts/ubench).  Spreading a rollout over the lanes of a quad cuts that stream to 125
+// instructions per step (round 1: 145) at 4x the (idle anyway) SIMD count.  Since round 3 this
+// kernel serves batches of 8193 .. 16384 rollouts; smaller ones run on the mirror-quad kernel
+// (swimmer_oct3.h: two quads per rollout with sine / cosine roles, 113 instructions per step):
 //
 //   lane q = 0,1,2 of a quad owns segment q: its angle, angular velocity, sin/cos, its row
 //   of the 3x3 joint-acceleration system and its V2 moment sums.  The joint torques are never
