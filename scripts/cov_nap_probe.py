@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import swimmer_amd as sw
 torch.cuda.set_stream(torch.cuda.Stream("cuda:0"))
-n, N, H = 6, 2048, 1000
+n, N, H = int(os.environ.get('PN', 6)), int(os.environ.get('PNDIR', 2048)), 1000
 res = {}
 for tag, kw in (("capture only", dict(full_covariance=False, record_trajectories=True)),
                 ("capture + ride-along pass", dict(full_covariance=True))):
@@ -24,5 +24,5 @@ for tag, kw in (("capture only", dict(full_covariance=False, record_trajectories
     torch.cuda.synchronize()
     res[tag] = a._pipe.rollout_ms()[0]
     del a
-print(f"SWIMMER_COV_NAP={os.environ.get('SWIMMER_COV_NAP', '0'):>3}: " + ", ".join(f"{k} {v:.4f} ms" for k, v in res.items())
+print(f"SWIMMER_COV_NAP={os.environ.get('SWIMMER_COV_NAP', '0'):>3} SWIMMER_COV_PRIO={os.environ.get('SWIMMER_COV_PRIO', '0')} n={n} N={N}: " + ", ".join(f"{k} {v:.4f} ms" for k, v in res.items())
       + f"; riding along costs {1e3 * (res['capture + ride-along pass'] - res['capture only']):+.1f} us", flush=True)
