@@ -70,7 +70,9 @@ constexpr int kMomGroup = 16;    // rollouts per V2 moment row (same partition i
 constexpr int64_t kQuadMaxRollouts = 16384;  // above this every SIMD already has a wave
 constexpr int64_t kRowMaxRollouts = 8192;    // row kernel (n >= 4): 4 rollouts per wave
 constexpr int kRowBlock = 256;               // 16 rollouts = one V2 moment row per workgroup
-constexpr int kUpdBlock = 256;
+constexpr int kUpdBlock = 256;        // update kernel: threads per workgroup up to kUpdWideFrom directions ...
+constexpr int kUpdBlockWide = 1024;   // ... and beyond (a thread's share of the directions stays short)
+constexpr int32_t kUpdWideFrom = 1025;
 constexpr int64_t kStepStreamBytes = (int64_t)256 << 20;   // beyond the Infinity Cache: nontemporal accesses
 constexpr double kHalfPi = 1.57079632679489661923;  // math.pi / 2 (remy_swimmer_env.py:65)
 constexpr double kTwinStart = 0.001;                // SwimmerEnvironment.cpp:41
@@ -1475,6 +1477,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
 
 // ------------------------------------------------------------------------------------
 // two sums with one pair of barriers (the update kernel is pure latency: every barrier counts)
+template <int BLOCK>
 __device__ __forceinline__ void block_sum2(double &a, double &b, double (*sh2)[2])
 {
 #pragma unroll
@@ -1490,7 +1493,7 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double (*sh2)[2
     }
     __syncthreads();
     double ta = 0.0, tb = 0.0;
-    for (int i = 0; i < kUpdBlock / kWave; ++i) {
+    for (int i = 0; i < BLOCK / kWave; ++i) {
         ta += sh2[i][0];
         tb += sh2[i][1];
     }
@@ -1541,14 +1544,15 @@ __device__ __forceinline__ bool rank_used_global(const GatherView &g, int32_t n_
 // then only touches LDS: ~5 us instead of ~17 us for the load-then-use-per-pass version.
 constexpr int kUpdMaxDirs = kTopBMaxDirs;
 
-__global__ void __launch_bounds__(kUpdBlock)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                   const double *__restrict__ deltas, double *__restrict__ policy, double alpha,
                   double b, int64_t top_b, double *__restrict__ running, double n_new,
                   double *__restrict__ mean, double *__restrict__ inv_std,
                   double *__restrict__ sigma_out)
 {
-    __shared__ double sh2[kUpdBlock / kWave][2];
+    __shared__ double sh2[BLOCK / kWave][2];
     __shared__ double rp_s[kUpdMaxDirs], rm_s[kUpdMaxDirs];   // r+ and r- of every direction
     __shared__ unsigned char flag[kUpdMaxDirs];
     const int e = blockIdx.x;
@@ -1556,21 +1560,21 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         const bool select = top_b > 0 && top_b < n_dir;
         const bool in_lds = n_dir <= kUpdMaxDirs;
         // one round of global loads: returns -> LDS, this workgroup's delta column -> registers
-        constexpr int kMaxPer = (kUpdMaxDirs + kUpdBlock - 1) / kUpdBlock;
+        constexpr int kMaxPer = (kUpdMaxDirs + BLOCK - 1) / BLOCK;
         double dcol[kMaxPer];
         if (in_lds) {
 #pragma unroll
             for (int q = 0; q < kMaxPer; ++q) {
-                const int32_t i = threadIdx.x + q * kUpdBlock;
+                const int32_t i = threadIdx.x + q * BLOCK;
                 dcol[q] = (i < n_dir) ? deltas[(int64_t)i * md + e] : 0.0;
             }
-            for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock) {
+            for (int32_t i = threadIdx.x; i < n_dir; i += BLOCK) {
                 rp_s[i] = ret_at(gv, i, 0);
                 rm_s[i] = ret_at(gv, i, 1);
             }
             __syncthreads();
             if (select) {
-                for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock) {
+                for (int32_t i = threadIdx.x; i < n_dir; i += BLOCK) {
                     const double ki = fmax(rp_s[i], rm_s[i]);
                     int32_t rank = 0;
                     for (int32_t j = 0; j < n_dir; ++j) {
@@ -1590,18 +1594,18 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         };
         // np.std(used_rewards): two-pass, ddof = 0 (ars_agent.py:123)
         double s = 0.0, cnt = 0.0;
-        for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+        for (int32_t i = threadIdx.x; i < n_dir; i += BLOCK)
             if (dir_used(i)) {
                 s += rplus(i) + rminus(i);
                 cnt += 2.0;
             }
-        block_sum2(s, cnt, sh2);
+        block_sum2<BLOCK>(s, cnt, sh2);
         const double mu = s / cnt;
         double v = 0.0, g = 0.0;
         if (in_lds) {
 #pragma unroll   // static index into dcol[] (a runtime index would send it to scratch)
             for (int q = 0; q < kMaxPer; ++q) {
-                const int32_t i = threadIdx.x + q * kUpdBlock;
+                const int32_t i = threadIdx.x + q * BLOCK;
                 if (i < n_dir && dir_used(i)) {
                     const double rp = rp_s[i], rm = rm_s[i];
                     const double a = rp - mu, c = rm - mu;
@@ -1610,7 +1614,7 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                 }
             }
         } else {
-            for (int32_t i = threadIdx.x; i < n_dir; i += kUpdBlock)
+            for (int32_t i = threadIdx.x; i < n_dir; i += BLOCK)
                 if (dir_used(i)) {
                     const double rp = rplus(i), rm = rminus(i);
                     const double a = rp - mu, c = rm - mu;
@@ -1618,7 +1622,7 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                     g = __builtin_fma(rp - rm, deltas[(int64_t)i * md + e], g);
                 }
         }
-        block_sum2(v, g, sh2);
+        block_sum2<BLOCK>(v, g, sh2);
         if (threadIdx.x == 0) {
             const double sigma = sqrt(v / cnt);
             // divisor: b as given (ars_agent.py:128: all directions used, b only divides), or with
@@ -1644,10 +1648,10 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
         // order.  Global row indices make the grouping -- and every bit of the result --
         // independent of the world size for row-aligned shards, and identical on every rank.
         constexpr int kMaxCols = 2 * (2 * SW_MAX_SEGMENTS + 2);     // 2d <= 36
-        constexpr int kMaxGroups = kUpdBlock / 12;                  // 2d >= 12 (n = 2): G <= 21 (16 for n = 3)
+        constexpr int kMaxGroups = BLOCK / 12;                  // 2d >= 12 (n = 2): G <= 21 (16 for n = 3)
         __shared__ double part[kMaxGroups][kMaxCols];
         __shared__ double bsum[kMaxCols];
-        const int cols = 2 * d, G = kUpdBlock / cols;
+        const int cols = 2 * d, G = BLOCK / cols;
         const int rg = threadIdx.x / cols, j = threadIdx.x - rg * cols;
         const int32_t total = gv.world * gv.rows_chunk;
         if (rg < G) {
@@ -2105,9 +2109,18 @@ static int launch_update(const sw_params *p, int64_t n_dir, const GatherView &gv
                          double *inv_std, double *sigma_out, void *stream)
 {
     const int d = 2 * p->n + 2, md = (p->n - 1) * d;
-    hipLaunchKernelGGL(ars_update_kernel, dim3(md + 1), dim3(kUpdBlock), 0, (hipStream_t)stream, d,
-                       md, (int32_t)n_dir, gv, deltas, policy, alpha, b, top_b, running,
-                       (double)n_new_states, mean, inv_std, sigma_out);
+    // The kernel is pure latency between two rollout launches; a thread's share of the directions (and of
+    // the moment rows) sets it.  256 threads per workgroup up to 1024 directions, 1024 beyond: 2048
+    // directions 11.6 -> ~6 us (rocprofv3).  The summation order is a function of n_dir only, so every
+    // rank of a sharded run and the single-process run of the same problem still get the same bits.
+    if (n_dir >= kUpdWideFrom)
+        hipLaunchKernelGGL(ars_update_kernel<kUpdBlockWide>, dim3(md + 1), dim3(kUpdBlockWide), 0,
+                           (hipStream_t)stream, d, md, (int32_t)n_dir, gv, deltas, policy, alpha, b, top_b,
+                           running, (double)n_new_states, mean, inv_std, sigma_out);
+    else
+        hipLaunchKernelGGL(ars_update_kernel<kUpdBlock>, dim3(md + 1), dim3(kUpdBlock), 0, (hipStream_t)stream,
+                           d, md, (int32_t)n_dir, gv, deltas, policy, alpha, b, top_b, running,
+                           (double)n_new_states, mean, inv_std, sigma_out);
     return launch_status();
 }
 
