@@ -317,6 +317,36 @@ def aux_step_only(sw, torch, n, device):
                     "algorithmic_GBps": byts / per / 1e9,
                     "hbm_frac": byts / per / 1e9 / HBM_PEAK_GBPS,
                     "frac_of_measured_copy_peak": byts / per / 1e9 / MEASURED_COPY_PEAK_GBPS}
+        if B == 8192:
+            # the launch-bound loop as ONE hipGraph launch: 100 steps ping-ponging two state buffers, captured
+            # from the same pre-bound launches (the library launches on the capturing stream like any other)
+            try:
+                back = sw.kernels.StepPlan(p, nxt, ac, st, rew)
+                side = torch.cuda.Stream(device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    fwd_s = sw.kernels.StepPlan(p, st, ac, nxt, rew)     # plans bind the stream current at creation
+                    back_s = sw.kernels.StepPlan(p, nxt, ac, st, rew)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side):
+                        for _ in range(50):
+                            fwd_s.launch()
+                            back_s.launch()
+                    for _ in range(3):
+                        graph.replay()
+                    side.synchronize()
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record()
+                    for _ in range(10):
+                        graph.replay()
+                    g1.record()
+                    side.synchronize()
+                gper = g0.elapsed_time(g1) * 1e-3 / 1000
+                out[tag].update(graph_us_per_step=gper * 1e6, graph_env_steps_per_s=B / gper,
+                                graph_note="100 step launches captured in one hipGraph, 10 replays")
+                del graph, back, fwd_s, back_s
+            except Exception as exc:   # noqa: BLE001 -- reported, the eager number stands
+                out[tag]["graph_error"] = f"{type(exc).__name__}: {exc}"
     return out
 
 
@@ -651,6 +681,7 @@ def summary(line, aux):
     out.update({
         "step8192_us": r3(dig(aux, "step_only", "envs_8192", "us_per_launch")),
         "step8192_sps": r3(dig(aux, "step_only", "envs_8192", "env_steps_per_s")),
+        "step8192_graph_us": r3(dig(aux, "step_only", "envs_8192", "graph_us_per_step")),
         "step4m_hbm_frac": r3(dig(aux, "step_only", "envs_4194304", "hbm_frac")),
         "sat262144_hbm_frac": r3(dig(aux, "rollout_saturated", "hbm_frac")),
         "sat65536_hbm_frac": r3(dig(aux, "rollout_saturated_65536", "hbm_frac")),
