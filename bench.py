@@ -165,11 +165,26 @@ class stdout_to_stderr(object):
 
 
 # ---------------------------------------------------------------------------------------
+_C_TOKEN = None
+
+
+def _strip_c_comments(text):
+    """C / C++ source with comments removed and runs of whitespace collapsed (string and character
+    literals are kept verbatim): what the compiler sees of it, so that editing a comment does not
+    make the measured traffic look stale."""
+    global _C_TOKEN
+    import re
+    if _C_TOKEN is None:
+        _C_TOKEN = re.compile(r'''("(?:\\.|[^"\\])*"|'(?:\\.|[^'\\])*')|(/\*.*?\*/|//[^\n]*)''', re.S)
+    out = _C_TOKEN.sub(lambda m: m.group(1) if m.group(1) else " ", text)
+    return " ".join(out.split())
+
+
 def kernel_source_hash():
     """sha256 over the sources libswimmer_hip.so is built from (csrc/*.hip, *.h, *.cpp and
-    include/*.h, by sorted name).  profiles/rNN_pmc_traffic.json stores the hash of the tree its
-    PMC passes ran on (scripts/pmc_traffic_json.py), so a kernel change without a new pass shows
-    as `traffic_stale` instead of silently printing last round's bytes."""
+    include/*.h, by sorted name; comments and whitespace stripped).  profiles/rNN_pmc_traffic.json
+    stores the hash of the tree its PMC passes ran on (scripts/pmc_traffic_json.py), so a kernel change
+    without a new pass shows as `traffic_stale` instead of silently printing last round's bytes."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -178,7 +193,7 @@ def kernel_source_hash():
                    glob.glob(os.path.join(pkg, "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
-        h.update(open(f, "rb").read())
+        h.update(_strip_c_comments(open(f, errors="replace").read()).encode())
     return h.hexdigest()
 
 

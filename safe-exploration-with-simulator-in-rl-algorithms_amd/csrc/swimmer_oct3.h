@@ -25,17 +25,17 @@
 //        cos(theta) = sin(theta + pi/2): the same table read at K + 1,
 // so a lane's DESIGNATED output (A: sin theta, B: cos theta) is one of the two polynomials of r with
 // a sign: the lane's coefficient set and the sign (in selS / selC) are state, re-chosen only when K
-// changes -- in the rare re-normalisation block, which is plain C++ here because it is entered from
-// a check made ONCE PER TRIP of four steps, not per step: |r| + 4 h |thetadot| > pi/4 (re-normalise now,
-// then run the trip unchecked).  During the trip r may leave [-pi/4, pi/4] by at most what the angle
-// travels in it, and a trip only runs unchecked if that is <= kTripSlack = 0.04 rad on every lane: the
-// polynomials stay accurate to 1.4e-16 up to pi/4 + 0.03 and 2.5e-16 up to pi/4 + 0.04 (1.2e-16 inside;
-// checked against long-double libm).  Trips with a faster lane (|thetadot| > 10 rad/s at h = 1e-3)
-// check inside every step, between the angle update and the evaluation: exact for ANY angular velocity.
+// changes -- in the rare re-normalisation block behind one vector compare, one scalar compare and one
+// untaken branch per step (oct3_range_test / oct3_keep_reduced), taken right after the angle update
+// and before the polynomial is evaluated: exact for any angular velocity.  (The row kernel, which
+// cannot afford the asm block's registers at n >= 6, checks once per trip of four steps instead and
+// runs trips whose angles travel more than kTripSlack = 0.04 rad in a loop that checks inside every
+// step; up to pi/4 + 0.04 the polynomials are accurate to 2.5e-16, 1.2e-16 inside, checked against
+// long-double libm.)
 //
 // Per step: 10 instructions of sin/cos + 2 moves instead of 20 + 4 of rotation, one barycentre sum
-// instead of two, no per-lane select for the recorded Gdot component
-// (scripts/isa_loop_stats.py).  The rollout's trajectory is quad A's copy of (theta, thetadot,
+// instead of two, no per-lane select for the recorded Gdot component: 113 instead of 124
+// (scripts/isa_loop_stats.py; SQ counters 112.7).  The rollout's trajectory is quad A's copy of (theta, thetadot,
 // Gdot_x) and quad B's Gdot_y.
 //
 // Same equations as swimmer_device.h (derivation there).  sin(r) = r + r z p(z) is the fdlibm form;
