@@ -58,3 +58,12 @@ def test_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     (prof / "r03_pmc_traffic.json").write_text(json.dumps({kern: {"traffic_bytes": 7}}))   # no hash recorded
     assert bench.pmc_traffic(kern, 3, 512, 1000)["stale"] is True
     assert bench.pmc_traffic(kern, 3, 256, 1000) is None           # another workload than the measured one
+
+
+def test_source_hash_ignores_comments_but_not_code(tmp_path, monkeypatch):
+    strip = bench._strip_c_comments
+    a = 'int a = 1; // note "x"\n/* block\n comment */ const char *s = "// kept /* kept */";  char c = \'"\';\n'
+    b = 'int a = 1;\nconst char *s = "// kept /* kept */"; char c = \'"\'; // another note\n'
+    assert strip(a) == strip(b)
+    assert strip(a) != strip(a.replace("a = 1", "a = 2"))
+    assert '"// kept /* kept */"' in strip(a)
