@@ -1210,7 +1210,6 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
     }
     if (t < H) one_step(G, Gn);
     thmax = fmax(thmax, fabs(th));
-    asm("v_max_f64 %0, %1, |%2|" : "=v"(thmax) : "v"(thmax), "v"(th));
 
     // ---- per-rollout outputs: quad A lanes 0..2 hold (theta, thetadot), A lane 0 Gdot_x, B lane 0 Gdot_y
     int code = ((det > 0.0) ? 0 : SW_STATUS_SINGULAR) |
@@ -1382,15 +1381,18 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             qgy = __builtin_fma(gdy, gdy, qgy);
         }
     };
-    // Range check once per trip of four steps, as in the mirror-quad kernel (see there): a trip whose
-    // angles move at most kTripSlack runs unchecked after one re-normalisation at its start if needed;
-    // a faster trip checks inside every step.  One step per loop body either way: unrolled, n >= 6
-    // would leave the 256 architectural registers.
+    // Range check once per trip of four steps (the mirror-quad kernel's per-step asm check would cost
+    // registers this kernel does not have at n >= 6): a trip whose angles move at most kTripSlack runs
+    // unchecked after one re-normalisation at its start if needed -- r ends at most that far past pi/4,
+    // where the polynomials are still accurate to 2.5e-16 (swimmer_oct3.h); a faster trip runs in the
+    // second loop, which checks inside every step (exact for any angular velocity).  One step per loop
+    // body either way: unrolled, n >= 6 would leave the 256 architectural registers.
     auto too_fast = [&]() -> bool {
         return __any((4.0 * C.h) * fabs(thd) > sw::kTripSlack);
     };
     int32_t t = 0;
-    while (t < H) {                                  // two loops, not one loop with two bodies (see the oct kernel)
+    while (t < H) {   // two loops, not one loop with two bodies: merged, the compiler reconciles the bodies'
+                      // register assignments with copies on the common path (profiles/r03_g_ab_range_check_variants.log)
         while (t < H) {                              // unchecked trips of (up to) four steps
             if (__builtin_expect(too_fast(), 0)) break;
             const double reach = __builtin_fma(4.0 * C.h, fabs(thd), fabs(A.r));

@@ -102,6 +102,12 @@ class DirectComm(object):
             self._lib.sw_comm_destroy(self._h)
             self._h = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
 
 class SingleEnv(object):
     """sw_env1: ONE swimmer handed over in host memory -- the batch-1 surface under
