@@ -487,7 +487,9 @@ struct CovTiling {
 // sums between them (moments_split): a tile is 64 rollouts wide and four times as long.
 __host__ __device__ constexpr bool cov_split(int D, int block) { return D >= 12 && block >= 256; }
 
-CovTiling cov_tiling(int64_t n_roll, int32_t H, int block, int D)
+// riding: the pass rides along in a rollout launch (or is the flush of a pass owed to one: same tiling,
+// same order of summation).  Otherwise it is the standalone pass of sw_traj_moments_f64, alone on the chip.
+CovTiling cov_tiling(int64_t n_roll, int32_t H, int block, int D, bool riding)
 {
     CovTiling t;
     const int cols = cov_split(D, block) ? kWave : block;   // rollouts per tile
@@ -498,6 +500,14 @@ CovTiling cov_tiling(int64_t n_roll, int32_t H, int block, int D)
     // 0.2798 ms with 64 steps per tile, 0.2663 with 128, 0.384 with 32; no difference at 512
     // directions; profiles/r02_f_cov_tile_sweep.log)
     int32_t base = (block >= kMomBlock) ? (cov_split(D, block) ? 4 * kMomTChunk : kMomTChunk) : 128;
+    if (!riding) {
+        // alone on the chip the pass is fastest with ~one workgroup per CU for the split tiles, one per two
+        // CUs for the wide ones -- fewer leave CUs idle, more lengthen the merge (0.06 us per tile):
+        // profiles/r03_p_cov_tchunk_sweep.log
+        const int64_t target = cov_split(D, block) ? 256 : 128;
+        const int64_t want = ((int64_t)H * t.nbx + target - 1) / target;
+        base = (int32_t)(want < 8 ? 8 : (want > H ? H : want));
+    }
     static const char *env = getenv("SWIMMER_COV_TCHUNK");   // measurement knob
     if (env && atoi(env) > 0) base = atoi(env);
     const uint32_t ny_max = (uint32_t)((H + base - 1) / base);
@@ -521,9 +531,23 @@ __host__ __device__ constexpr int cov_sums(int D) { return 1 + D + D * D; }
 // workgroups that ride along in a rollout launch (SideJob).  For long chains the upper triangle is
 // accumulated JB rows at a time (re-reading the tile from cache) so that the accumulators stay in
 // registers.
+// A tile's row of partial sums inside the pass's scratch.  The scratch is stored TRANSPOSED -- entry j of
+// tile i at [j * n_tiles + i] -- so that the merge reads one entry of consecutive tiles with consecutive
+// lanes (moments_tile); a tile's own stores are strided (fire and forget).
+struct TileRow {
+    double *p;
+    int64_t stride;
+    // agent-scope store (written through the XCD's L2): visible to the merging workgroup on another XCD once
+    // the store has completed, without a write-back of everything else that is dirty in this L2
+    __device__ __forceinline__ void put(int j, double v) const
+    {
+        __hip_atomic_store(p + (int64_t)j * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 template <int D, int BLOCK, int J0, int JB>
 __device__ __forceinline__ void moments_pass(int64_t n_roll, const double *__restrict__ traj,
-                                             double *__restrict__ tile_row, int64_t bx, int32_t t0, int32_t t1,
+                                             const TileRow tile_row, int64_t bx, int32_t t0, int32_t t1,
                                              double *sh /* [BLOCK / 64][D + JB * D] */)
 {
     constexpr int NW = BLOCK / kWave, W = D + JB * D;
@@ -573,15 +597,15 @@ __device__ __forceinline__ void moments_pass(int64_t n_roll, const double *__res
         if (!live) continue;
         double v = 0.0;
         for (int i = 0; i < NW; ++i) v += sh[i * W + j];   // fixed order over the waves
-        if (j < D) tile_row[j] = v;
-        else tile_row[D + f * D + g] = v;                   // upper triangle only
+        if (j < D) tile_row.put(j, v);
+        else tile_row.put(D + f * D + g, v);                // upper triangle only
     }
 }
 
 template <int D, int BLOCK, int JB, int J0 = 0>
 struct MomentsPasses {
     static __device__ __forceinline__ void run(int64_t n_roll, const double *__restrict__ traj,
-                                               double *__restrict__ tile_row, int64_t bx, int32_t t0,
+                                               const TileRow tile_row, int64_t bx, int32_t t0,
                                                int32_t t1, double *sh)
     {
         if constexpr (J0 < D) {
@@ -631,19 +655,19 @@ __device__ __forceinline__ void moments_item_add(double &a, const double (&x)[D]
 }
 
 template <int D, int Q>
-__device__ __forceinline__ void moments_item_store(double v, double *__restrict__ tile_row)
+__device__ __forceinline__ void moments_item_store(double v, const TileRow tile_row)
 {
     if constexpr (Q < D) {
-        tile_row[Q] = v;
+        tile_row.put(Q, v);
     } else {
         constexpr int f = pair_row(D, Q - D), g = pair_col(D, Q - D);
-        tile_row[D + f * D + g] = v;   // upper triangle only
+        tile_row.put(D + f * D + g, v);   // upper triangle only
     }
 }
 
 template <int D, int WV, int... I>
 __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double *__restrict__ traj,
-                                                   double *__restrict__ tile_row, int64_t bx, int32_t t0,
+                                                   const TileRow tile_row, int64_t r0, int32_t t0,
                                                    int32_t t1, int32_t nap, std::integer_sequence<int, I...>)
 {
     constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4, Q0 = WV * PER;
@@ -651,30 +675,51 @@ __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double 
     // the lowest state column this wave multiplies: columns below it are never loaded
     constexpr int JMIN = (Q0 < D) ? 0 : pair_row(D, Q0 - D);
     const int l = threadIdx.x % kWave;
-    const int64_t r = bx * kWave + l;
     double acc[CNT];
 #pragma unroll
     for (int q = 0; q < CNT; ++q) acc[q] = 0.0;
+    // buffer loads: the step's slab base (wave-uniform, scalar arithmetic) is the resource's base, the
+    // column is the scalar offset, the lane the 32-bit vector offset -- no per-lane 64-bit address
+    // arithmetic in the loop.  One slab (D n_roll doubles) is < 4 GiB for every supported n_roll.
+    const uint32_t lane_bytes = (uint32_t)l * 8u;
+    const uint32_t col_bytes = (uint32_t)(n_roll * 8);
     auto load = [&](double (&x)[D], int32_t t) {
-        const double *tp = traj + (int64_t)t * D * n_roll + r;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(traj + ((int64_t)t * D * n_roll + r0)), 0, (int)0xffffffffu, 0x00020000);
 #pragma unroll
         for (int j = JMIN; j < D; ++j) {
             const double c = (j >= 2 && (j & 1) == 0) ? kHalfPi : 0.0;
-            x[j] = tp[(int64_t)j * n_roll] - c;
+            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+            union { v2u i; double d; } u;
+            u.i = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_bytes, (int)((uint32_t)j * col_bytes), 0);
+            x[j] = u.d - c;
         }
     };
-    if (r < n_roll && t0 < t1) {
-        double xa[D], xb[D];
-        load(xa, t0);
-        for (int32_t t = t0; t < t1; t += 2) {
-            if (t + 1 < t1) load(xb, t + 1);
-            (moments_item_add<D, Q0 + I>(acc[I], xa), ...);
-            if (t + 2 < t1) load(xa, t + 2);
-            if (t + 1 < t1) (moments_item_add<D, Q0 + I>(acc[I], xb), ...);
-            // riding along in a rollout launch that fills the chip: pace the loads so that this wave's
-            // requests do not crowd the CU's memory pipeline in front of the rollout waves' stores
-            for (int32_t z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
+    if (r0 + l < n_roll && t0 < t1) {
+        // THREE steps' loads in flight (a riding wave is alone with its memory latency: the tile's time is
+        // steps x latency / depth), no conditionals in the steady state (they cost register copies).  Every
+        // accumulator still adds its steps in order: the sums do not depend on the depth.
+        double xa[D], xb[D], xc[D];
+        auto add = [&](const double (&x)[D]) { (moments_item_add<D, Q0 + I>(acc[I], x), ...); };
+        int32_t t = t0;
+        load(xa, t);
+        if (t + 1 < t1) load(xb, t + 1);
+        for (; t + 4 < t1; t += 3) {     // xa, xb hold steps t, t + 1
+            load(xc, t + 2);
+            add(xa);
+            load(xa, t + 3);
+            add(xb);
+            load(xb, t + 4);
+            add(xc);
+            for (int32_t z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);   // measurement knob (SWIMMER_COV_NAP)
         }
+        const int32_t left = t1 - t;     // 1..4 steps, xa (and xb if left >= 2) loaded
+        if (left >= 3) load(xc, t + 2);
+        add(xa);
+        if (left >= 4) load(xa, t + 3);
+        if (left >= 2) add(xb);
+        if (left >= 3) add(xc);
+        if (left >= 4) add(xa);
     }
 #pragma unroll
     for (int q = 0; q < CNT; ++q) {
@@ -686,24 +731,24 @@ __device__ __forceinline__ void moments_split_wave(int64_t n_roll, const double 
 
 template <int D, int WV>
 __device__ __forceinline__ void moments_split_part(int64_t n_roll, const double *__restrict__ traj,
-                                                   double *__restrict__ tile_row, int64_t bx, int32_t t0,
-                                                   int32_t t1, int32_t nap)
+                                                   const TileRow tile_row, int64_t r0, int32_t t0, int32_t t1,
+                                                   int32_t nap)
 {
     constexpr int ITEMS = D + D * (D + 1) / 2, PER = (ITEMS + 3) / 4, Q0 = WV * PER;
     constexpr int CNT = (Q0 + PER <= ITEMS) ? PER : ITEMS - Q0;
-    moments_split_wave<D, WV>(n_roll, traj, tile_row, bx, t0, t1, nap, std::make_integer_sequence<int, CNT>{});
+    moments_split_wave<D, WV>(n_roll, traj, tile_row, r0, t0, t1, nap, std::make_integer_sequence<int, CNT>{});
 }
 
 template <int D>
-__device__ __forceinline__ void moments_split(int64_t n_roll, const double *__restrict__ traj,
-                                              double *__restrict__ tile_row, int64_t bx, int32_t t0, int32_t t1,
-                                              int32_t nap)
+__device__ __forceinline__ void moments_split(int64_t n_roll, const double *__restrict__ traj, const TileRow tile_row,
+                                              int64_t bx, int32_t t0, int32_t t1, int32_t nap)
 {
-    switch (threadIdx.x / kWave) {   // wave-uniform
-    case 0: moments_split_part<D, 0>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
-    case 1: moments_split_part<D, 1>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
-    case 2: moments_split_part<D, 2>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
-    default: moments_split_part<D, 3>(n_roll, traj, tile_row, bx, t0, t1, nap); break;
+    const int64_t r0 = bx * kWave;
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x / kWave)) {   // scalar: the waves' addresses stay uniform
+    case 0: moments_split_part<D, 0>(n_roll, traj, tile_row, r0, t0, t1, nap); break;
+    case 1: moments_split_part<D, 1>(n_roll, traj, tile_row, r0, t0, t1, nap); break;
+    case 2: moments_split_part<D, 2>(n_roll, traj, tile_row, r0, t0, t1, nap); break;
+    default: moments_split_part<D, 3>(n_roll, traj, tile_row, r0, t0, t1, nap); break;
     }
 }
 
@@ -718,37 +763,77 @@ __device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const do
     constexpr int JB = (D <= 12) ? D : (D == 14 ? 7 : (D == 16 ? 6 : 5));
     constexpr int W = D + D * D;
     __shared__ uint32_t ticket;
-    double *rows = acc + cov_sums(D) + 1;
+    double *rows = acc + cov_sums(D) + 1;              // [W][n_tiles]
+    const TileRow row{rows + tile, (int64_t)n_tiles};
     if constexpr (cov_split(D, BLOCK)) {
         static_assert(BLOCK == 4 * kWave, "moments_split: four waves per workgroup");
-        moments_split<D>(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1, nap);
+        moments_split<D>(n_roll, traj, row, bx, t0, t1, nap);
     } else {
         __shared__ double sh[(BLOCK / kWave) * (D + JB * D)];
-        MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, rows + (int64_t)tile * W, bx, t0, t1, sh);
+        MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, row, bx, t0, t1, sh);
     }
-    __threadfence();   // this tile's row is visible device-wide before its ticket is
+    // the row's stores are agent-scope (TileRow::put): once they have completed (the workgroup-scope fence
+    // waits for them) the row is visible device-wide, before this tile's ticket is.  No device-scope release
+    // here: it would write back the whole L2 -- in a rollout launch that is the trajectories -- per tile.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
         ticket = atomicAdd(reinterpret_cast<uint32_t *>(acc + cov_sums(D)), 1u);
     __syncthreads();
     if (ticket != n_tiles - 1u) return;
-    // last tile to finish: add every tile's row to acc, in tile order (four interleaved partial
-    // sums per entry, combined in a fixed tree)
+    // Last tile to finish: add every tile's row to acc.  The merge is a chain of memory latencies (the
+    // rows were written by other XCDs: every load misses), so it is laid out for loads in flight, not
+    // for arithmetic: a wave takes kMergeEntries entries at a time, lane l of it the tiles l, l + 64, ...
+    // of each (consecutive lanes = consecutive addresses), four interleaved partial sums per lane, then a
+    // shuffle tree over the lanes; the totals meet in LDS and are added to acc by one thread per entry
+    // (one more latency, not one per group).  The order depends on n_tiles only, never on which tile
+    // ran last.
     __threadfence();
-    for (int j = threadIdx.x; j < W; j += BLOCK) {
-        const int f = (j - D) / D, g = (j - D) % D;
-        if (j >= D && g < f) continue;
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
-        uint32_t t = 0;
-        for (; t + 4 <= n_tiles; t += 4) {
+    constexpr int kMergeEntries = 8, NWV = BLOCK / kWave, ITEMS = D + D * (D + 1) / 2;
+    __shared__ double merged[ITEMS];
+    const int w = threadIdx.x / kWave, l = threadIdx.x % kWave;
+    for (int q0 = w * kMergeEntries; q0 < ITEMS; q0 += NWV * kMergeEntries) {
+        const double *col[kMergeEntries];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] += rows[(int64_t)(t + q) * W + j];
+        for (int e = 0; e < kMergeEntries; ++e) {
+            const int q = (q0 + e < ITEMS) ? q0 + e : ITEMS - 1;       // the last group repeats an entry
+            const int j = (q < D) ? q : D + pair_row(D, q - D) * D + pair_col(D, q - D);
+            col[e] = rows + (int64_t)j * n_tiles;
         }
-        for (int q = 0; t < n_tiles; ++t, ++q) a[q] += rows[(int64_t)t * W + j];
-        const double v = (a[0] + a[1]) + (a[2] + a[3]);
-        if (j < D) {
-            acc[1 + j] += v;
+        double a[kMergeEntries][4];
+#pragma unroll
+        for (int e = 0; e < kMergeEntries; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[e][i] = 0.0;
+        uint32_t t = (uint32_t)l;
+        for (; t + 3u * kWave < n_tiles; t += 4u * kWave) {
+#pragma unroll
+            for (int e = 0; e < kMergeEntries; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[e][i] += col[e][t + (uint32_t)(i * kWave)];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (t + (uint32_t)(i * kWave) < n_tiles) {
+#pragma unroll
+                for (int e = 0; e < kMergeEntries; ++e) a[e][i] += col[e][t + (uint32_t)(i * kWave)];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < kMergeEntries; ++e) {
+            double v = (a[e][0] + a[e][1]) + (a[e][2] + a[e][3]);
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+            if (l == 0 && q0 + e < ITEMS) merged[q0 + e] = v;
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < ITEMS; q += BLOCK) {
+        const double v = merged[q];
+        if (q < D) {
+            acc[1 + q] += v;
         } else {   // mirror into both halves
+            const int f = pair_row(D, q - D), g = pair_col(D, q - D);
             acc[1 + D + f * D + g] += v;
             if (g != f) acc[1 + D + g * D + f] += v;
         }
@@ -1864,7 +1949,7 @@ unsigned side_attach_cov(SideJob &sj, unsigned roll_blocks, int block, int sj_D)
         sj.first_cov_block = UINT32_MAX;
         return 0;
     }
-    const CovTiling t = cov_tiling(sj.cov_rolls, sj.cov_H, block, sj_D);
+    const CovTiling t = cov_tiling(sj.cov_rolls, sj.cov_H, block, sj_D, true);
     sj.cov_nbx = t.nbx;
     sj.cov_tchunk = t.tchunk;
     sj.cov_tiles = t.nbx * t.ny;
@@ -2170,12 +2255,12 @@ int sw_ars_update_gathered_f64(const sw_params *p, int64_t n_dir, const double *
 // it still owes with the block size of the rollout kernel that would have carried it, so a flushed
 // pass sums in exactly the order the ride-along pass would have (bit-identical resume).
 static int launch_traj_moments(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
-                               double *acc, int block, void *stream)
+                               double *acc, int block, bool riding, void *stream)
 {
     if (n_roll < 0 || H < 0) return SW_ERR_SIZE;
     if (n_roll == 0 || H == 0) return SW_OK;
     if (!traj || !acc) return SW_ERR_NULL;
-    const CovTiling t = cov_tiling(n_roll, H, block, 2 * p->n + 2);
+    const CovTiling t = cov_tiling(n_roll, H, block, 2 * p->n + 2, riding);
     const dim3 grid(t.nbx * t.ny);
     if (block == kRollBlock) {
         SW_DISPATCH_N(p->n, hipLaunchKernelGGL((traj_moments_kernel<2 * NN + 2, kRollBlock>), grid,
@@ -2199,11 +2284,12 @@ int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H)
     const int d = 2 * p->n + 2;
     int64_t tiles = 0;
     if (n_roll > 0 && H > 0) {
-        const CovTiling a = cov_tiling(n_roll, H, kRollBlock, d), b = cov_tiling(n_roll, H, kMomBlock, d),
-                        c = cov_tiling(n_roll, H, kOctBlock, d);
-        const int64_t ta = (int64_t)a.nbx * a.ny, tb = (int64_t)b.nbx * b.ny, tc = (int64_t)c.nbx * c.ny;
-        tiles = ta > tb ? ta : tb;
-        tiles = tc > tiles ? tc : tiles;
+        for (int riding = 0; riding < 2; ++riding)
+            for (int block : {kRollBlock, kOctBlock, kMomBlock}) {
+                const CovTiling t = cov_tiling(n_roll, H, block, d, riding != 0);
+                const int64_t n = (int64_t)t.nbx * t.ny;
+                tiles = n > tiles ? n : tiles;
+            }
     }
     return cov_sums(d) + 1 + tiles * (d + d * d);
 }
@@ -2213,7 +2299,7 @@ int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const dou
 {
     int rc = check_params(p);
     if (rc) return rc;
-    return launch_traj_moments(p, n_roll, H, traj, acc, kMomBlock, stream);
+    return launch_traj_moments(p, n_roll, H, traj, acc, kMomBlock, false, stream);
 }
 
 // ---- one swimmer per call (include/swimmer_hip.h, sw_env1) -----------------------------
@@ -2365,7 +2451,7 @@ int flush_owed_cov(sw_ars_pipeline *pl, hipStream_t stream)
 {
     if (!pl->cov_traj) return SW_OK;
     const int rc = launch_traj_moments(&pl->cov_params, pl->cov_rolls, pl->cov_H, pl->cov_traj,
-                                       pl->cov_acc, pl->cov_block, stream);
+                                       pl->cov_acc, pl->cov_block, true, stream);
     pl->cov_traj = nullptr;
     return rc;
 }

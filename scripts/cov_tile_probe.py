@@ -1,0 +1,52 @@
+"""Standalone covariance pass and ride-along cost for the tile length given by SWIMMER_COV_TCHUNK (read once
+per process): separates the tiles' own work from the serial merge of the tile rows (its length = the
+number of tiles).  PN / PNDIR: segments / directions.  Design aid."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import swimmer_amd as sw
+from swimmer_amd import kernels
+torch.cuda.set_stream(torch.cuda.Stream("cuda:0"))
+n, N, H = int(os.environ.get('PN', 6)), int(os.environ.get('PNDIR', 2048)), 1000
+p = sw.SwParams.make(n)
+R = 2 * N
+traj = torch.randn((H, p.d, R), dtype=torch.float64, device="cuda:0")
+acc = kernels.new_cov_acc(p, R, H, "cuda:0")
+for _ in range(3):
+    kernels.traj_moments(p, traj, acc)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    kernels.traj_moments(p, traj, acc)
+e1.record()
+torch.cuda.synchronize()
+alone = e0.elapsed_time(e1) / 10
+del traj, acc
+if os.environ.get("STANDALONE_ONLY"):
+    print(f"SWIMMER_COV_TCHUNK={os.environ.get('SWIMMER_COV_TCHUNK', 'default'):>7} n={n} N={N}: standalone {alone * 1e3:6.1f} us", flush=True)
+    sys.exit(0)
+res = {}
+for tag, kw in (("capture only", dict(full_covariance=False, record_trajectories=True)),
+                ("capture + ride-along pass", dict(full_covariance=True))):
+    ep = sw.EnvParam("B", n=n, H=H, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+    ap = sw.ARSParam("B", V1=False, n_iter=0, H=H, N=N, b=N, alpha=0.0075, nu=0.01, safe=False,
+                     threshold=0, initial_w="Zero")
+    a = sw.ARSAgent(ep, ap, seed=0, device="cuda:0", **kw)
+    # capture only: keep the trajectory stores, drop the per-iteration clone into the store (a 0.46 GB copy
+    # between two launches lets the chip's power budget recover and flatters the next launch by ~10 %)
+    a.record_trajectories = False
+    for _ in range(30):
+        a.run_iteration_async(want_returns=False)
+        a.database._device_batches.clear()
+    torch.cuda.synchronize()
+    a._pipe.timing(1)
+    for _ in range(10):
+        a.run_iteration_async(want_returns=False)
+        a.database._device_batches.clear()
+    torch.cuda.synchronize()
+    res[tag] = a._pipe.rollout_ms()[0]
+    del a
+print(f"SWIMMER_COV_TCHUNK={os.environ.get('SWIMMER_COV_TCHUNK', 'default'):>7} n={n} N={N}: standalone {alone * 1e3:6.1f} us; "
+      + ", ".join(f"{k} {v:.4f} ms" for k, v in res.items())
+      + f"; riding along costs {1e3 * (res['capture + ride-along pass'] - res['capture only']):+.1f} us", flush=True)
