@@ -654,13 +654,15 @@ def collective_one_rank_child(args):
     print(json.dumps(res), flush=True)
 
 
-def aux_ars_shard(sw, torch, n, H, directions, device, iters=12):
+def aux_ars_shard(sw, torch, n, H, directions, device, iters=24, warm=10):
     """One GPU's shard of a sharded config (configs[3]: n = 3, configs[4]: n = 6; 2048
     directions over 8 GPUs = 256 per GPU) as a self-contained ARS iteration loop."""
     import numpy as np
     state = np.random.get_state()
     leg = ArsLeg(sw, torch, n, H, directions, device)
-    r = leg.run(3, iters, torch.cuda.synchronize, time_every=4, postpass=8)
+    # ten warm-up iterations: a full-chip f64 launch only settles at its sustained clock after a few
+    # milliseconds of load (2048 directions, n = 6: 0.78 ms per iteration after 3 warm-ups, 0.67 after 10)
+    r = leg.run(warm, iters, torch.cuda.synchronize, time_every=4, postpass=8)
     leg.check(0)
     np.random.set_state(state)
     dt = r["seconds"] / iters

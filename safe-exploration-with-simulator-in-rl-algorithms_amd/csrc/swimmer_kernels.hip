@@ -41,6 +41,28 @@
 #include "swimmer_row.h"
 #include "swimmer_twin.h"
 
+// Where a rollout kernel's hot loop starts inside a 64-byte line of code.  A lone wave's issue rate depends on
+// it: the same instructions, byte for byte, ran 0.2267 and 0.2346 ms per launch (n = 3) after an unrelated
+// change elsewhere in the file had moved the loop by 16 bytes, and the one-step loops of the row kernel lose
+// 4-11 % when their head is not 8-byte aligned (profiles/r03_p_ab_n3.log, r03_p_loop_pad_sweep_*.log).
+// SW_PIN_LOOP aligns the code that follows to a line and puts PAD s_nops (4 bytes each) behind the boundary;
+// the pads below are the best of a sweep over 0..7 on the GPU (scripts/ab_probe.sh over builds with
+// -DSW_OCT_LOOP_PAD=k -DSW_QUAD_LOOP_PAD=k -DSW_ROW_LOOP_PAD=k).  Sweep again after changing what lies
+// between a pin and its loop.
+#define SW_PIN_LOOP(PAD) asm volatile(".p2align 6\n\t.fill %0, 4, 0xbf800000" ::"n"(PAD))
+#ifndef SW_OCT_LOOP_PAD
+#define SW_OCT_LOOP_PAD 2
+#endif
+#ifndef SW_QUAD_LOOP_PAD
+#define SW_QUAD_LOOP_PAD 0
+#endif
+// row kernel, n = 4..8 (index n - 4); -DSW_ROW_LOOP_PAD=k overrides all five for a sweep
+#ifdef SW_ROW_LOOP_PAD
+constexpr int kRowLoopPad[5] = {SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD};
+#else
+constexpr int kRowLoopPad[5] = {5, 0, 5, 6, 1};
+#endif
+
 // steps per trip of the quad kernel's loop (measurement knob; 2 measured +5 ns per step)
 #ifndef SW_QUAD_UNROLL
 #define SW_QUAD_UNROLL 4
@@ -1099,6 +1121,7 @@ rollout_quad3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__re
     // four steps per trip, the geometry ping-pongs between G and Gn (no register copies)
     int32_t t = 0;
 #if SW_QUAD_UNROLL == 4
+    SW_PIN_LOOP(SW_QUAD_LOOP_PAD);
     for (; t + 4 <= H; t += 4) {
         one_step(G, Gn);
         one_step(Gn, G);
@@ -1283,6 +1306,7 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
     };
     // four steps per trip, the geometry ping-pongs between G and Gn (no register copies)
     int32_t t = 0;
+    SW_PIN_LOOP(SW_OCT_LOOP_PAD);
     for (; t + 4 <= H; t += 4) {
         one_step(G, Gn);
         one_step(Gn, G);
@@ -1476,6 +1500,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         return __any((4.0 * C.h) * fabs(thd) > sw::kTripSlack);
     };
     int32_t t = 0;
+    SW_PIN_LOOP(kRowLoopPad[N - 4]);
     while (t < H) {   // two loops, not one loop with two bodies: merged, the compiler reconciles the bodies'
                       // register assignments with copies on the common path (profiles/r03_g_ab_range_check_variants.log)
         while (t < H) {                              // unchecked trips of (up to) four steps
