@@ -436,12 +436,16 @@ def aux_next_rows(sw, torch, device, n=3, H=1000, directions=512):
     est = Estimator(agent.database, ep, capacity=2 * directions, device=device)
     est.I([1.0, 1.0, 10.0])
     torch.cuda.synchronize()
-    reps, t0 = 20, time.perf_counter()
-    for i in range(reps):
+    samples = []
+    for i in range(40):
+        t0 = time.perf_counter()
         est.I([1.0 + 1e-3 * i, 1.0, 10.0])      # .item() inside: host-synchronous, like CMA-ES uses it
-    dt = (time.perf_counter() - t0) / reps
+        samples.append(time.perf_counter() - t0)
+    # median: one host hiccup (a 38 ms stall was seen once in 20 evaluations) would own the mean
+    dt = sorted(samples)[len(samples) // 2]
     T = 2 * directions * (H - 1)
     out["estimator_objective"] = {"transitions": T, "us_per_evaluation": dt * 1e6,
+                                  "us_mean": sum(samples) / len(samples) * 1e6, "us_max": max(samples) * 1e6,
                                   "transitions_per_s": T / dt,
                                   "note": "Estimator.I(x): one step-kernel launch over every stored transition "
                                           "of a device-resident store + norm reduction + .item()"}
