@@ -688,9 +688,15 @@ def summary(line, aux):
         return None if x is None else float(f"{x:.4g}")
 
     roof = line["roofline"]
-    out = {"n3_ms": r3(line["ms_per_step"]), "n3_sps": r3(line["value"]), "n3_kernel_ms": r3(roof.get("kernel_ms")),
-           "n3_hbm_frac": r3(roof.get("frac")), "n3_issue_frac": r3(roof.get("issue_bound_frac")),
-           "n3_instr": roof.get("instructions_per_step"), "traffic_stale": roof.get("traffic_stale")}
+    m = f"n{dig(line, 'config', 'segments') or 3}"      # the main leg's keys carry its chain length (default 3)
+    out = {m + "_ms": r3(line["ms_per_step"]), m + "_sps": r3(line["value"]), m + "_kernel_ms": r3(roof.get("kernel_ms")),
+           m + "_hbm_frac": r3(roof.get("frac")), m + "_issue_frac": r3(roof.get("issue_bound_frac")),
+           m + "_instr": roof.get("instructions_per_step"), "traffic_stale": roof.get("traffic_stale")}
+    if dig(line, "n_gpus") not in (None, 1):
+        out["n_gpus"] = line["n_gpus"]
+        out["collective_us"] = r3(dig(aux, "collective_us"))
+        out["strong2048_ms"] = r3(dig(aux, "strong_2048_directions", "ms_per_iteration"))
+        out["strong2048_sps"] = r3(dig(aux, "strong_2048_directions", "env_steps_per_s"))
     for tag, key in (("n3_sh256", "shard_n3_256_directions"), ("n6_sh256", "shard_n6_256_directions"),
                      ("n3_2048_1gpu", "ars_2048_directions_one_gpu"), ("n6_2048_1gpu", "ars_2048_directions_one_gpu_n6")):
         out[tag + "_ms"] = r3(dig(aux, key, "ms_per_iteration"))

@@ -35,6 +35,11 @@ def test_summary_is_flat_short_and_last():
                 "n3_2048_1gpu_ms", "n6_2048_1gpu_over_priced", "step8192_us", "step4m_hbm_frac",
                 "sat262144_hbm_frac", "sat65536_hbm_frac", "coll1_us", "gym_step_us", "rlglue_step_us"):
         assert key in sm
+    assert sm["n3_ms"] == 0.2602 and "n_gpus" not in sm                   # main leg: n = 3 unless the config says otherwise
+    multi = dict(line, n_gpus=8, config={"segments": 6})
+    sm8 = bench.summary(multi, {"collective_us": 21.5, "strong_2048_directions": {"ms_per_iteration": 0.51,
+                                                                               "env_steps_per_s": 8.0e9}})
+    assert sm8["n6_ms"] == 0.2602 and sm8["n_gpus"] == 8 and sm8["collective_us"] == 21.5 and sm8["strong2048_ms"] == 0.51
     # a leg that failed ({"error": ...}) drops its keys instead of raising
     aux["shard_n6_256_directions"] = {"error": "boom"}
     assert "n6_sh256_ms" not in bench.summary(line, aux)
