@@ -334,6 +334,20 @@ def test_covariance_pass_on_ragged_tiles(sw, n, R, H):
     assert np.array_equal(acc, sw.kernels.traj_moments(p, traj)[:1 + d + d * d].cpu().numpy())
 
 
+def test_covariance_pass_hand_over_under_repetition(sw):
+    """The pass hands its tiles' rows to the merging workgroup without a device-scope release per tile
+    (agent-scope stores, then the ticket): 216 passes over nine shapes (wide and split tiles, one tile to
+    several hundred, both tilings' merges), each twice into fresh accumulators -- same bits -- and against
+    the sums torch computes in fp64.  A stale or missing row would be a gross error, not a rounding one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "cov_stress", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "cov_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    passes, worst = mod.run(6)
+    assert passes == 216 and worst < 1e-9
+
+
 @pytest.mark.parametrize("n", [3, 6])
 @pytest.mark.parametrize("kernel", ["lane", "quad"])
 def test_fast_spinning_segments_stay_exact(sw, n, kernel):
