@@ -34,6 +34,7 @@
 #include <utility>
 #include <vector>
 
+#include <chrono>
 #include "../../include/swimmer_hip.h"
 #include "swimmer_device.h"
 #include "swimmer_quad3.h"
@@ -2460,13 +2461,23 @@ __global__ void flag_kernel(uint32_t *flag, uint32_t value)
 int wait_flag(const sw_ars_pipeline *pl, uint32_t need)
 {
     const volatile uint32_t *f = pl->flag_host;
+    // Health check of the stream (instead of spinning forever behind a faulted launch) only after 20 ms
+    // without progress, then every 20 ms: hipStreamQuery is NOT free for the device -- to learn whether
+    // the last kernel is done the runtime enqueues a marker (a barrier packet with a system-scope release)
+    // behind it, and the next rollout launch then starts 5.9 us late.  Queried every ~50 us of spinning,
+    // as until round 3, that was one marker per iteration: 233.1 -> 227 us per iteration at the headline
+    // config (profiles/r03_u_gap_probe.log).
+    auto last = std::chrono::steady_clock::now();
     for (int64_t spins = 0;; ++spins) {
         if ((int32_t)(*f - need) >= 0) return SW_OK;
         if ((spins & 0xfff) == 0xfff) {
-            // not hot any more: make sure the stream is still healthy instead of spinning forever
-            const hipError_t q = hipStreamQuery(pl->last_main);
-            if (q == hipSuccess) return ((int32_t)(*f - need) >= 0) ? SW_OK : SW_ERR_LAUNCH;
-            if (q != hipErrorNotReady) return SW_ERR_LAUNCH;
+            const auto now = std::chrono::steady_clock::now();
+            if (now - last >= std::chrono::milliseconds(20)) {
+                last = now;
+                const hipError_t q = hipStreamQuery(pl->last_main);
+                if (q == hipSuccess) return ((int32_t)(*f - need) >= 0) ? SW_OK : SW_ERR_LAUNCH;
+                if (q != hipErrorNotReady) return SW_ERR_LAUNCH;
+            }
         }
         __builtin_ia32_pause();
     }
