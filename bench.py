@@ -670,10 +670,15 @@ def aux_ars_shard(sw, torch, n, H, directions, device, iters=24, warm=10):
     # ten warm-up iterations: a full-chip f64 launch only settles at its sustained clock after a few
     # milliseconds of load (2048 directions, n = 6: 0.78 ms per iteration after 3 warm-ups, 0.67 after 10)
     r = leg.run(warm, iters, torch.cuda.synchronize, time_every=4, postpass=8)
+    # median of three timed rounds (the main leg times exactly K steps once, as the contract says; these
+    # legs can afford to shrug off a stall of the box or a busy host)
+    rounds = [r["seconds"]] + [leg.run(0, iters, torch.cuda.synchronize, time_every=4, postpass=0)["seconds"]
+                               for _ in range(2)]
     leg.check(0)
     np.random.set_state(state)
-    dt = r["seconds"] / iters
+    dt = sorted(rounds)[1] / iters
     return {"segments": n, "directions": directions, "ms_per_iteration": dt * 1e3,
+            "ms_rounds": [x / iters * 1e3 for x in rounds],
             "env_steps_per_s": 2 * directions * H / dt,
             "roofline": leg_roofline(n, directions, H, r["kernel_ms"])}
 
