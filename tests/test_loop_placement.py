@@ -1,0 +1,65 @@
+"""Where the rollout kernels' hot loops sit inside their 64-byte code line (csrc/swimmer_kernels.hip,
+SW_PIN_LOOP).  A lone wave's issue rate depends on it -- the same instructions ran 3.5 % (n = 3) to 11 %
+(n = 7) apart at different offsets -- and the offset of an unpinned loop moves with every unrelated edit
+earlier in the file.  This test reads the offsets out of the built library and compares them with the ones
+the sweep on the GPU chose (profiles/r03_p_loop_pad_sweep_*.log, r03_q_final_pads.log).  If it fails after
+a change to a kernel (or a new compiler), the loop has moved relative to its pin: run the sweep again
+(scripts/ab_probe.sh over builds with -DSW_OCT_LOOP_PAD=k -DSW_QUAD_LOOP_PAD=k -DSW_ROW_LOOP_PAD=k) and
+update the pads and this table."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "safe-exploration-with-simulator-in-rl-algorithms_amd", "csrc", "libswimmer_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernel (mangled-name fragment) -> (bytes of the hot loop's body, offset of its head inside a 64-byte line)
+EXPECTED = {
+    "rollout_oct3_kernelILb1ELb1ELb1E": (2928, 16),     # four steps per trip; 16 = the 0.2255 ms point of the sweep
+    "rollout_row_kernelILi4ELb1ELb1ELb1E": (1200, 0),
+    "rollout_row_kernelILi5ELb1ELb1ELb1E": (1468, 32),
+    "rollout_row_kernelILi6ELb1ELb1ELb1E": (1752, 28),
+    "rollout_row_kernelILi7ELb1ELb1ELb1E": (2048, 0),
+    "rollout_row_kernelILi8ELb1ELb1ELb1E": (2452, 56),
+}
+
+
+def _disassemble(tmp_path):
+    fat, elf = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.elf")
+    subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", LIB, fat], check=True)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={elf}"], check=True)
+    return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", elf], check=True,
+                          capture_output=True, text=True).stdout.split("\n")
+
+
+def _backward_loops(lines, fragment):
+    """(head address, body bytes, branch mnemonic) of every backward branch of the kernel."""
+    start = next(i for i, l in enumerate(lines) if fragment in l and l.endswith(">:"))
+    out = []
+    for l in lines[start + 1:]:
+        if l.startswith("0000"):
+            break
+        m = re.match(r"\s+(s_c?branch\w*)\s+(\d+)\s.*//\s*([0-9A-Fa-f]+):", l)
+        if not m:
+            continue
+        off, addr = int(m.group(2)), int(m.group(3), 16)
+        if off >= 32768:
+            off -= 65536
+            out.append((addr + 4 + 4 * off, -4 * off, m.group(1)))
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and shutil.which(f"{LLVM}/llvm-objdump")),
+                    reason="needs the built library and the ROCm llvm tools")
+def test_hot_loops_sit_where_the_sweep_put_them(tmp_path):
+    lines = _disassemble(tmp_path)
+    for fragment, (body, where) in EXPECTED.items():
+        loops = [(h, b) for h, b, op in _backward_loops(lines, fragment) if b == body and op == "s_cbranch_scc0"]
+        assert len(loops) == 1, (fragment, "hot loop of", body, "bytes not found: the kernel's code changed", loops)
+        head = loops[0][0]
+        assert head % 64 == where, (fragment, "hot loop head at", head % 64, "of its 64-byte line, the sweep chose", where)
