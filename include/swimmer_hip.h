@@ -181,10 +181,11 @@ int sw_ars_update_gathered_f64(const sw_params *p, int64_t n_dir, const double *
  * acc[0] += count, acc[1..d] += sum(s - c), acc[1+d + f*d + g] += sum((s-c)_f (s-c)_g),
  * over traj [H][d][n_roll].  HBM-bound: reads the trajectory buffer exactly once.
  * acc holds sw_cov_acc_doubles(p, n_roll, H) doubles: the 1 + d + d*d sums, then the pass's
- * scratch (a ticket counter and one row of partial sums per tile); the caller zeroes ALL of it
- * before the first call and leaves the scratch part alone afterwards.  No floating-point atomics:
- * the tile that finishes last adds the rows in tile order, so the same call on the same data
- * gives the same bits.  Passes over one acc must be stream-ordered (one at a time). */
+ * scratch (a ticket counter and the tiles' partial sums, laid out [entry][tile]); the caller zeroes
+ * ALL of it before the first call and leaves the scratch part alone afterwards.  No floating-point
+ * atomics: the tile that finishes last merges the partial sums in an order that depends on the
+ * number of tiles only, so the same call on the same data gives the same bits.  Passes over one acc
+ * must be stream-ordered (one at a time). */
 int64_t sw_cov_acc_doubles(const sw_params *p, int64_t n_roll, int32_t H);
 int sw_traj_moments_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *traj,
                         double *acc, void *stream);
