@@ -1508,21 +1508,6 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
             if (__builtin_expect(too_fast(), 0)) break;
             const double reach = __builtin_fma(4.0 * C.h, fabs(thd), fabs(A.r));
             if (__builtin_expect(__any(reach > sw::kPio4), 0)) sw::oct3_renorm(A, designation, thmax);
-#ifdef SW_ROW_TRIP_STRAIGHT
-            if (t + 4 <= H) {   // the trip's four steps as straight-line code: no taken branch between them; the
-                                // scheduling barriers keep each step's registers to itself (as in the rolled loop)
-                one_step(std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                one_step(std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                one_step(std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                one_step(std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                t += 4;
-                continue;
-            }
-#endif
             const int32_t t_end = min(H, t + 4);
 #pragma unroll 1
             for (; t < t_end; ++t) one_step(std::false_type{});
