@@ -51,8 +51,11 @@
 // -DSW_OCT_LOOP_PAD=k -DSW_QUAD_LOOP_PAD=k -DSW_ROW_LOOP_PAD=k).  Sweep again after changing what lies
 // between a pin and its loop.
 #define SW_PIN_LOOP(PAD) asm volatile(".p2align 6\n\t.fill %0, 4, 0xbf800000" ::"n"(PAD))
+#ifndef SW_OCT_UNROLL
+#define SW_OCT_UNROLL 8   // steps per trip of the mirror-quad kernel's main loop (4 or 8)
+#endif
 #ifndef SW_OCT_LOOP_PAD
-#define SW_OCT_LOOP_PAD 2
+#define SW_OCT_LOOP_PAD 5
 #endif
 #ifndef SW_QUAD_LOOP_PAD
 #define SW_QUAD_LOOP_PAD 0
@@ -1305,9 +1308,23 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
         w2 = sw::dpp_f64<sw::kDppNext2>(thd);
         Pv = sw::dpp_row_f64<sw::kDppRowRor8>(Pu);
     };
-    // four steps per trip, the geometry ping-pongs between G and Gn (no register copies)
+    // the geometry ping-pongs between G and Gn (no register copies): an even number of steps per trip
     int32_t t = 0;
     SW_PIN_LOOP(SW_OCT_LOOP_PAD);
+#if SW_OCT_UNROLL == 8
+    // eight steps per trip: the loop's back edge costs a lone wave ~8-13 ns (2 / 4 / 8 steps per trip:
+    // 0.2292 / 0.2272 / 0.2250 ms per launch, each at its best loop offset; profiles/r03_t, r03_w)
+    for (; t + 8 <= H; t += 8) {
+        one_step(G, Gn);
+        one_step(Gn, G);
+        one_step(G, Gn);
+        one_step(Gn, G);
+        one_step(G, Gn);
+        one_step(Gn, G);
+        one_step(G, Gn);
+        one_step(Gn, G);
+    }
+#endif
     for (; t + 4 <= H; t += 4) {
         one_step(G, Gn);
         one_step(Gn, G);

@@ -19,7 +19,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # kernel (mangled-name fragment) -> (bytes of the hot loop's body, offset of its head inside a 64-byte line)
 EXPECTED = {
-    "rollout_oct3_kernelILb1ELb1ELb1E": (2928, 16),     # four steps per trip; 16 = the 0.2255 ms point of the sweep
+    "rollout_oct3_kernelILb1ELb1ELb1E": (5840, 56),     # eight steps per trip; 56 = the 0.2245 ms point of the sweep
     "rollout_row_kernelILi4ELb1ELb1ELb1E": (1200, 0),
     "rollout_row_kernelILi5ELb1ELb1ELb1E": (1468, 32),
     "rollout_row_kernelILi6ELb1ELb1ELb1E": (1752, 28),
