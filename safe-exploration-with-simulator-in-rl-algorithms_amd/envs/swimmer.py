@@ -132,7 +132,12 @@ class SwimmerEnv(object):
     # parameters are plain attributes in the reference and may be reassigned between
     # calls (ars/estimator.py builds envs per candidate), so the struct is rebuilt lazily
     def _params(self):
-        return SwParams.make(self.n, self.l_i, self.m_i, self.k, self.h, self.direction)
+        d = self.direction
+        key = (self.n, self.l_i, self.m_i, self.k, self.h, float(d[0]), float(d[1]))
+        if key != getattr(self, "_params_key", None):   # rebuilt only when an attribute was reassigned
+            self._params_key = key
+            self._params_struct = SwParams.make(self.n, self.l_i, self.m_i, self.k, self.h, d)
+        return self._params_struct
 
     def _handover(self, torque, G_dot, theta, theta_dot):
         """State and action into the handle's host-mapped I/O block (kernels.SingleEnv)."""
