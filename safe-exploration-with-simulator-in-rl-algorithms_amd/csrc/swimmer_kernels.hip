@@ -54,17 +54,26 @@
 #ifndef SW_OCT_UNROLL
 #define SW_OCT_UNROLL 8   // steps per trip of the mirror-quad kernel's main loop (4 or 8)
 #endif
-#ifndef SW_OCT_LOOP_PAD
-#define SW_OCT_LOOP_PAD 5
+// mirror-quad kernel, by what the loop carries (trajectory capture, V2 moment sums): every instantiation is
+// its own code, with its own best offset (profiles/r03_x_inst_sweep.log); -DSW_OCT_LOOP_PAD=k overrides all four
+#ifdef SW_OCT_LOOP_PAD
+constexpr int oct_loop_pad(bool, bool) { return SW_OCT_LOOP_PAD; }
+#else
+constexpr int oct_loop_pad(bool traj, bool mom) { return traj ? (mom ? 5 : 6) : (mom ? 6 : 2); }
 #endif
 #ifndef SW_QUAD_LOOP_PAD
 #define SW_QUAD_LOOP_PAD 0
 #endif
-// row kernel, n = 4..8 (index n - 4); -DSW_ROW_LOOP_PAD=k overrides all five for a sweep
+// row kernel, n = 4..8; swept with capture + moments for every n, and for the other three forms at n = 6;
+// -DSW_ROW_LOOP_PAD=k overrides all of them for a sweep
 #ifdef SW_ROW_LOOP_PAD
-constexpr int kRowLoopPad[5] = {SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD, SW_ROW_LOOP_PAD};
+constexpr int row_loop_pad(int, bool, bool) { return SW_ROW_LOOP_PAD; }
 #else
-constexpr int kRowLoopPad[5] = {5, 0, 5, 6, 1};
+constexpr int row_loop_pad(int n, bool traj, bool mom)
+{
+    if (n == 6 && !(traj && mom)) return traj ? 6 : 4;
+    return n == 4 ? 5 : n == 5 ? 0 : n == 6 ? 5 : n == 7 ? 6 : 1;
+}
 #endif
 
 // steps per trip of the quad kernel's loop (measurement knob; 2 measured +5 ns per step)
@@ -1310,7 +1319,7 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
     };
     // the geometry ping-pongs between G and Gn (no register copies): an even number of steps per trip
     int32_t t = 0;
-    SW_PIN_LOOP(SW_OCT_LOOP_PAD);
+    SW_PIN_LOOP(oct_loop_pad(TRAJ, MOM));
 #if SW_OCT_UNROLL == 8
     // eight steps per trip: the loop's back edge costs a lone wave ~8-13 ns (2 / 4 / 8 steps per trip:
     // 0.2292 / 0.2272 / 0.2250 ms per launch, each at its best loop offset; profiles/r03_t, r03_w)
@@ -1518,7 +1527,7 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
         return __any((4.0 * C.h) * fabs(thd) > sw::kTripSlack);
     };
     int32_t t = 0;
-    SW_PIN_LOOP(kRowLoopPad[N - 4]);
+    SW_PIN_LOOP(row_loop_pad(N, TRAJ, MOM));
     while (t < H) {   // two loops, not one loop with two bodies: merged, the compiler reconciles the bodies'
                       // register assignments with copies on the common path (profiles/r03_g_ab_range_check_variants.log)
         while (t < H) {                              // unchecked trips of (up to) four steps

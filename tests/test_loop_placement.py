@@ -20,9 +20,15 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # kernel (mangled-name fragment) -> (bytes of the hot loop's body, offset of its head inside a 64-byte line)
 EXPECTED = {
     "rollout_oct3_kernelILb1ELb1ELb1E": (5840, 56),     # eight steps per trip; 56 = the 0.2245 ms point of the sweep
+    "rollout_oct3_kernelILb1ELb0ELb1E": (5588, 28),     # V2 without capture
+    "rollout_oct3_kernelILb1ELb0ELb0E": (5236, 0),      # V1 without capture
+    "rollout_oct3_kernelILb1ELb1ELb0E": (5548, 40),     # V1 with capture
     "rollout_row_kernelILi4ELb1ELb1ELb1E": (1200, 0),
     "rollout_row_kernelILi5ELb1ELb1ELb1E": (1468, 32),
     "rollout_row_kernelILi6ELb1ELb1ELb1E": (1752, 28),
+    "rollout_row_kernelILi6ELb1ELb0ELb1E": (1712, 4),
+    "rollout_row_kernelILi6ELb1ELb0ELb0E": (1676, 4),
+    "rollout_row_kernelILi6ELb1ELb1ELb0E": (1712, 56),
     "rollout_row_kernelILi7ELb1ELb1ELb1E": (2048, 0),
     "rollout_row_kernelILi8ELb1ELb1ELb1E": (2452, 56),
 }
