@@ -231,7 +231,24 @@ def calibrate_issue_intervals(sw, device):
         ISSUE_NS["source"] += f" (live calibration not used: {exc})"
 
 
-def issue_bound(n, H, kern_ms):
+FULL_CHIP_NS = {}     # waves per workgroup of the probe grid -> {"f64": ns, "other": ns}
+
+
+def full_chip_intervals(sw, device, waves):
+    """The two issue intervals with `256 x waves` probe waves on the chip (4: one on every SIMD, what the n = 6 /
+    2048-direction launch does; 2: every other SIMD, the n = 3 / 2048-direction launch), measured after the
+    chip has settled under that load (kernels.issue_interval_full_chip_ns)."""
+    if waves not in FULL_CHIP_NS:
+        try:
+            f64 = sw.kernels.issue_interval_full_chip_ns(0, device, waves=waves)
+            other = sw.kernels.issue_interval_full_chip_ns(1, device, waves=waves)
+            FULL_CHIP_NS[waves] = {"f64": f64, "other": other} if (1.0 < f64 < 8.0 and 1.0 < other < 8.0) else None
+        except Exception:   # noqa: BLE001 -- the line then carries the idle-chip pricing only
+            FULL_CHIP_NS[waves] = None
+    return FULL_CHIP_NS[waves]
+
+
+def issue_bound(n, H, kern_ms, full_chip=None):
     """The rollout kernel's real ceiling: every wave runs alone on its SIMD and issues ONE
     instruction per ~2 ns, so a rollout batch cannot finish faster than H x instructions per
     step x the shortest issue interval there is (floor_ms), whatever the batch size.  priced_ms
@@ -244,12 +261,21 @@ def issue_bound(n, H, kern_ms):
     fastest = min(ISSUE_NS["f64"], ISSUE_NS["other"])
     floor_ms = H * (f64 + other) * fastest * 1e-6
     priced_ms = H * (f64 * ISSUE_NS["f64"] + other * ISSUE_NS["other"]) * 1e-6
-    return {"instructions_per_step": f64 + other, "f64_instructions_per_step": f64,
-            "lone_wave_ns_per_f64_instruction": ISSUE_NS["f64"],
-            "lone_wave_ns_per_other_instruction": ISSUE_NS["other"],
-            "intervals": ISSUE_NS["source"],
-            "floor_ms": floor_ms, "frac": floor_ms / kern_ms,
-            "priced_ms": priced_ms, "measured_over_priced": kern_ms / priced_ms}
+    out = {"instructions_per_step": f64 + other, "f64_instructions_per_step": f64,
+           "lone_wave_ns_per_f64_instruction": ISSUE_NS["f64"],
+           "lone_wave_ns_per_other_instruction": ISSUE_NS["other"],
+           "intervals": ISSUE_NS["source"],
+           "floor_ms": floor_ms, "frac": floor_ms / kern_ms,
+           "priced_ms": priced_ms, "measured_over_priced": kern_ms / priced_ms}
+    if full_chip:
+        # the same mix priced with the intervals a wave sees while the WHOLE chip issues (lower sustained
+        # clock): what is left above 1 here is contention inside the launch (the covariance waves sharing
+        # SIMDs with the rollout waves), not the chip's power budget
+        fc_ms = H * (f64 * full_chip["f64"] + other * full_chip["other"]) * 1e-6
+        out.update({"full_chip_ns_per_f64_instruction": full_chip["f64"],
+                    "full_chip_ns_per_other_instruction": full_chip["other"],
+                    "priced_ms_full_chip": fc_ms, "measured_over_priced_full_chip": kern_ms / fc_ms})
+    return out
 
 
 def rollout_kernel_name(n):
@@ -520,7 +546,7 @@ def aux_next_rows(sw, torch, device, n=3, H=1000, directions=512):
     return out
 
 
-def aux_rollout_saturated(sw, torch, device, n=3, n_roll=262144, H=1000, reps=3):
+def aux_rollout_saturated(sw, torch, device, n=3, n_roll=262144, H=1000, reps=15):
     """Where the ROLLOUT path is HBM-bound: the lane-per-rollout kernel on a batch that fills the
     chip (262 144 rollouts x H = 1000) with every post-step state captured, 16.8 GB of stores."""
     import numpy as np
@@ -530,20 +556,28 @@ def aux_rollout_saturated(sw, torch, device, n=3, n_roll=262144, H=1000, reps=3)
     pol = torch.as_tensor(0.01 * (2 * rng.rand(4096, m, d) - 1), device=device).repeat(n_roll // 4096, 1, 1)
     traj = torch.empty((H, d, n_roll), dtype=torch.float64, device=device)
     rets = torch.empty(n_roll, dtype=torch.float64, device=device)
-    sw.kernels.rollout(p, H, pol, traj=traj, returns=rets)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    # Median of `reps` launches, each with its own events, after three warm-up launches.  Until round 3 this
+    # leg timed THREE launches after ONE warm-up, wherever the legs before it had left the chip's clocks: on
+    # one box the same binary then reads 0.51 .. 0.61 of the HBM peak at 65 536 rollouts (idle before / full
+    # load before; profiles/r04_a_lane_ab.log), which is all the "slide" of this number over round 3 was --
+    # the kernel's machine code is identical to round 2's.
+    for _ in range(3):
         sw.kernels.rollout(p, H, pol, traj=traj, returns=rets)
-    e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record()
+        sw.kernels.rollout(p, H, pol, traj=traj, returns=rets)
+        e1.record()
+    torch.cuda.synchronize()
+    samples = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    ms = samples[len(samples) // 2]
     byts = n_roll * H * 8 * d + n_roll * (8 * m * d + 8)
     del traj
     torch.cuda.empty_cache()
     return {"kernel": f"rollout_kernel<{n},false,false> (one rollout per lane)",
             "rollouts": n_roll, "horizon": H, "trajectory_capture": True, "ms": ms,
+            "ms_min": samples[0], "ms_max": samples[-1], "launches": reps,
             "env_steps_per_s": n_roll * H / (ms * 1e-3), "algorithmic_bytes": byts,
             "achieved_GBps": byts / (ms * 1e-3) / 1e9,
             "hbm_frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
@@ -600,13 +634,13 @@ class ArsLeg(object):
             raise SystemExit(f"rank {rank}: bench produced {bad} bad rollouts / non-finite policy")
 
 
-def leg_roofline(n, n_local, H, kern_ms):
+def leg_roofline(n, n_local, H, kern_ms, full_chip=None):
     alg = rollout_algorithmic_bytes(n, n_local, H)
     ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms else None
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBPS if ach else None, "algorithmic_bytes": alg,
             "kernel": rollout_kernel_name(n), "kernel_ms": kern_ms,
-            "issue_bound": issue_bound(n, H, kern_ms)}
+            "issue_bound": issue_bound(n, H, kern_ms, full_chip)}
 
 
 def aux_collective_one_rank(n, H, directions, timeout=150, direct=False):
@@ -661,7 +695,7 @@ def collective_one_rank_child(args):
     print(json.dumps(res), flush=True)
 
 
-def aux_ars_shard(sw, torch, n, H, directions, device, iters=24, warm=10):
+def aux_ars_shard(sw, torch, n, H, directions, device, iters=24, warm=10, probe_waves=0):
     """One GPU's shard of a sharded config (configs[3]: n = 3, configs[4]: n = 6; 2048
     directions over 8 GPUs = 256 per GPU) as a self-contained ARS iteration loop."""
     import numpy as np
@@ -677,10 +711,50 @@ def aux_ars_shard(sw, torch, n, H, directions, device, iters=24, warm=10):
     leg.check(0)
     np.random.set_state(state)
     dt = sorted(rounds)[1] / iters
+    # probe_waves: price the launch with the intervals of a chip that is as full as this launch makes it
+    # (measured right here, while the chip is still warm from the leg)
+    fc = full_chip_intervals(sw, device, probe_waves) if probe_waves else None
     return {"segments": n, "directions": directions, "ms_per_iteration": dt * 1e3,
             "ms_rounds": [x / iters * 1e3 for x in rounds],
             "env_steps_per_s": 2 * directions * H / dt,
-            "roofline": leg_roofline(n, directions, H, r["kernel_ms"])}
+            "roofline": leg_roofline(n, directions, H, r["kernel_ms"], fc)}
+
+
+def aux_host_cost(sw, torch, device, gpu_ms):
+    """Host time per pipelined ARS iteration at the sizes an 8-rank job puts on EVERY rank's host (every rank
+    draws every direction's noise: ars_agent.py:137-138 runs once per direction, serially, in the reference):
+    with H = 10 the GPU needs a few microseconds per iteration, so the loop time IS the host time (native
+    MT19937 stream + pinned H2D + two launches + Python).  `host_bound` = the host needs more than 0.8 x the
+    GPU iteration of that rank's shard: the ranks would then wait for their own hosts, not for each other."""
+    import time
+    import numpy as np
+    state = np.random.get_state()
+    out = {}
+    for tag, n, N, shard_key in (("n3_4096_directions", 3, 4096, "n3"), ("n6_2048_directions", 6, 2048, "n6"),
+                                 ("n6_4096_directions", 6, 4096, "n6")):
+        ep = sw.EnvParam("LeonSwimmer-Host", n=n, H=10, l_i=1.0, m_i=1.0, h=1e-3, k=10.0, epsilon=0)
+        ap = sw.ARSParam("Host", V1=False, n_iter=0, H=10, N=N, b=N, alpha=0.0075, nu=0.01,
+                         safe=False, threshold=0, initial_w="Zero")
+        ag = sw.ARSAgent(ep, ap, seed=0, device=device, full_covariance=True)
+        for _ in range(150):
+            ag.run_iteration_async(want_returns=False)
+        torch.cuda.synchronize()
+        rounds = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(150):
+                ag.run_iteration_async(want_returns=False)
+            rounds.append((time.perf_counter() - t0) / 150 * 1e6)
+            torch.cuda.synchronize()
+        host_us = sorted(rounds)[1]
+        g = gpu_ms.get(shard_key)
+        out[tag] = {"host_us_per_iteration": host_us, "us_rounds": rounds,
+                    "noise_doubles_per_iteration": N * (n - 1) * (2 * n + 2),
+                    "gpu_us_per_iteration_of_a_rank": None if g is None else g * 1e3,
+                    "host_bound": None if g is None else bool(host_us > 0.8 * g * 1e3)}
+        del ag
+    np.random.set_state(state)
+    return out
 
 
 def summary(line, aux):
@@ -713,6 +787,9 @@ def summary(line, aux):
         out[tag + "_hbm_frac"] = r3(dig(aux, key, "roofline", "frac"))
         out[tag + "_issue_frac"] = r3(dig(aux, key, "roofline", "issue_bound", "frac"))
         out[tag + "_over_priced"] = r3(dig(aux, key, "roofline", "issue_bound", "measured_over_priced"))
+        if "2048" in tag:
+            out[tag + "_over_priced_full_chip"] = r3(dig(aux, key, "roofline", "issue_bound",
+                                                         "measured_over_priced_full_chip"))
     out.update({
         "step8192_us": r3(dig(aux, "step_only", "envs_8192", "us_per_launch")),
         "step8192_sps": r3(dig(aux, "step_only", "envs_8192", "env_steps_per_s")),
@@ -725,6 +802,12 @@ def summary(line, aux):
         "coll1_ms": r3(dig(aux, "collective_one_rank", "ms_per_iteration")),
         "coll1_direct_us": r3(dig(aux, "collective_one_rank_direct", "collective_us")),
         "coll1_direct_ms": r3(dig(aux, "collective_one_rank_direct", "ms_per_iteration")),
+        "host_us_n3_4096": r3(dig(aux, "host_cost_at_8_ranks", "n3_4096_directions", "host_us_per_iteration")),
+        "host_us_n6_2048": r3(dig(aux, "host_cost_at_8_ranks", "n6_2048_directions", "host_us_per_iteration")),
+        "host_us_n6_4096": r3(dig(aux, "host_cost_at_8_ranks", "n6_4096_directions", "host_us_per_iteration")),
+        "host_bound_n3_4096": dig(aux, "host_cost_at_8_ranks", "n3_4096_directions", "host_bound"),
+        "host_bound_n6_2048": dig(aux, "host_cost_at_8_ranks", "n6_2048_directions", "host_bound"),
+        "host_bound_n6_4096": dig(aux, "host_cost_at_8_ranks", "n6_4096_directions", "host_bound"),
         "gym_step_us": r3(dig(aux, "single_env", "gym_step_us")),
         "env1_step_us": r3(dig(aux, "single_env", "env1_step_us")),
         "rlglue_step_us": r3(dig(aux, "single_env", "rlglue_env_step_us")),
@@ -904,13 +987,21 @@ def run_rank(args):
         if not args.no_aux and world == 1:
             aux["step_only"] = guarded(aux_step_only, sw, torch, n, device)
             # configs[3]'s whole problem on ONE GPU
-            aux["ars_2048_directions_one_gpu"] = guarded(aux_ars_shard, sw, torch, n, H, 2048, device)
+            aux["ars_2048_directions_one_gpu"] = guarded(aux_ars_shard, sw, torch, n, H, 2048, device,
+                                                         probe_waves=(2 if n == 3 else 4))
             if n != 6:   # configs[4]'s whole problem on ONE GPU (4096 rollouts = a wave on every SIMD)
-                aux["ars_2048_directions_one_gpu_n6"] = guarded(aux_ars_shard, sw, torch, 6, H, 2048, device)
+                aux["ars_2048_directions_one_gpu_n6"] = guarded(aux_ars_shard, sw, torch, 6, H, 2048, device,
+                                                                probe_waves=4)
             aux["shard_n3_256_directions"] = guarded(aux_ars_shard, sw, torch, 3, H, 256, device)
             aux["shard_n6_256_directions"] = guarded(aux_ars_shard, sw, torch, 6, H, 256, device)
             aux["collective_one_rank"] = guarded(aux_collective_one_rank, n, H, args.directions)
             aux["collective_one_rank_direct"] = guarded(aux_collective_one_rank, n, H, args.directions, direct=True)
+            # what every rank's HOST does per iteration at the 8-rank sizes, against the GPU iteration of a rank
+            # (n = 3: this line's main leg, 512 directions per GPU; n = 6: the 256-direction shard -- the launch
+            # time is the same up to 512 directions of n = 6, a wave on every fourth SIMD)
+            gpu_ms = {"n3": dt / args.steps * 1e3 if n == 3 else None,
+                      "n6": (aux.get("shard_n6_256_directions") or {}).get("ms_per_iteration")}
+            aux["host_cost_at_8_ranks"] = guarded(aux_host_cost, sw, torch, device, gpu_ms)
             aux["next_rows"] = guarded(aux_next_rows, sw, torch, device)
             aux["rollout_saturated"] = guarded(aux_rollout_saturated, sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster

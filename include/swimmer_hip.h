@@ -211,7 +211,8 @@ typedef struct sw_env1 sw_env1;
 int sw_env1_create(sw_env1 **out);
 void sw_env1_destroy(sw_env1 *e);
 /* A handle is used by one thread at a time (it owns one I/O block and one sequence counter) and
- * belongs to the device that was current when it was created.
+ * belongs to the device that was current when it was created: sw_env1_step / sw_env1_accel launch on that
+ * device whatever the caller's current device is, and leave the caller's current device unchanged.
  * HOST pointer to the handle's I/O block (SW_ENV1_DOUBLES doubles), valid until destroy. */
 double *sw_env1_io(sw_env1 *e);
 /* One physics step of the swimmer in the block (model chosen by p->flags); BLOCKING: the
@@ -247,14 +248,24 @@ const char *sw_comm_last_error(sw_comm *c);
  * ceiling of the latency-bound rollout kernels (one instruction per ~2 ns for a lone wave) on the
  * device it runs on.  Replaces nothing in the reference. */
 int sw_issue_probe(int32_t mode, int32_t trips, double *scratch64, void *stream);
+/* The same with `workgroups` x `waves_per_workgroup` (1..4) such waves at once: 256 x 4 puts one wave on
+ * every SIMD of an MI355X, i.e. the intervals with the whole chip issuing (a chip full of f64 work sustains
+ * a lower clock than a lone wave sees: bench.py prices the full-chip launches with these). */
+int sw_issue_probe_grid(int32_t mode, int32_t trips, int32_t workgroups, int32_t waves_per_workgroup,
+                        double *scratch64, void *stream);
 
 /* ---- host helper: the reference's random stream ----------------------------------------
  * out[i] = 2*u_i - 1 with u_i the next doubles of NumPy's legacy MT19937 generator
  * (np.random.rand), continuing from the state (key[624], *pos) in the form
  * np.random.get_state() / set_state() use; the state is advanced in place.  Replaces the
- * N calls of 2*np.random.rand(m, d)-1 in ars/ars_agent.py:137-138 (same values, 5-8x
- * faster, so the host keeps ahead of the GPU at any rank count).  HOST pointers. */
+ * N calls of 2*np.random.rand(m, d)-1 in ars/ars_agent.py:137-138 (same values, an order of
+ * magnitude faster, so the host keeps ahead of the GPU at any rank count).  HOST pointers.
+ * The vector width (baseline x86-64 / AVX2 / AVX-512) is chosen at run time from the CPU's features;
+ * every width produces the same bits. */
 int sw_mt19937_uniform_pm1(uint32_t *key, int32_t *pos, int64_t n, double *out);
+/* Test hook: run the stream at a given width (0 baseline, 1 AVX2, 2 AVX-512; -1 = widest available, the
+ * default); a width the CPU lacks falls back to the next one down.  Returns the width that will run. */
+int sw_mt19937_force_isa(int level);
 
 /* ---- ARS iteration pipeline (host-side enqueue logic in native code) ------------------
  * Replaces the serial body of ARSAgent.runOneIteration (ars/ars_agent.py:137-182) with a

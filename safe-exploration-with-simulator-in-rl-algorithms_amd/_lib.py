@@ -97,8 +97,11 @@ _PROTOTYPES = {
                                               ctypes.c_int64, ctypes.c_void_p]),
     "sw_comm_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "sw_issue_probe": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "sw_issue_probe_grid": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_void_p]),
     "sw_mt19937_uniform_pm1": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
                                               ctypes.c_int64, ctypes.c_void_p]),
+    "sw_mt19937_force_isa": (ctypes.c_int, [ctypes.c_int]),
     "sw_ars_pipeline_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "sw_ars_pipeline_destroy": (None, [ctypes.c_void_p]),
     "sw_ars_pipeline_slots": (ctypes.c_int, []),

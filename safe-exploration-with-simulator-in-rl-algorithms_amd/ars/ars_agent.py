@@ -145,7 +145,10 @@ class ARSAgent(object):
         if direct_rccl and (self.world > 1 or _sh._FORCE_COLLECTIVE):
             if self.world > 1 and dist.get_backend(self.group) != "nccl":
                 raise SwimmerHipError("direct_rccl needs GPU ranks (backend nccl), one per device")
-            self._comm = kernels.DirectComm(self.world, self.rank, self._broadcast_bytes)
+            # the communicator binds to the CURRENT device: make it this agent's (a torchrun job that never
+            # called torch.cuda.set_device would otherwise put every rank's communicator on GPU 0)
+            with torch.cuda.device(self.device):
+                self._comm = kernels.DirectComm(self.world, self.rank, self._broadcast_bytes, self._all_ranks_ok)
 
         # Randomness: the reference seeds NumPy's global generator (ars_agent.py:94-95)
         self.n_seed = seed
@@ -161,6 +164,14 @@ class ARSAgent(object):
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast(t, src=src, group=self.group)
         return bytes(t.cpu().numpy().tobytes())
+
+    def _all_ranks_ok(self, ok):
+        """COLLECTIVE: True when `ok` holds on every rank of the group."""
+        if self.world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
 
     def _exchange(self):
         if self._comm is not None:

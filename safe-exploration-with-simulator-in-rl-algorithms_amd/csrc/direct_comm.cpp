@@ -11,6 +11,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <initializer_list>
 #include <new>
 
 #include "../../include/swimmer_hip.h"

@@ -807,9 +807,13 @@ __device__ __forceinline__ void moments_tile(int64_t n_roll, int32_t H, const do
         __shared__ double sh[(BLOCK / kWave) * (D + JB * D)];
         MomentsPasses<D, BLOCK, JB>::run(n_roll, traj, row, bx, t0, t1, sh);
     }
-    // the row's stores are agent-scope (TileRow::put): once they have completed (the workgroup-scope fence
-    // waits for them) the row is visible device-wide, before this tile's ticket is.  No device-scope release
+    // The row's stores are agent-scope write-through stores (TileRow::put): once they have COMPLETED the row is
+    // visible device-wide.  Every wave therefore waits for its own stores (s_waitcnt vmcnt(0): a workgroup-scope
+    // release fence does NOT emit that wait on gfx950) before the barrier behind which thread 0 takes the ticket,
+    // so the ticket can never become visible before the row has reached memory.  No device-scope release
     // here: it would write back the whole L2 -- in a rollout launch that is the trajectories -- per tile.
+    // (tests/test_isa_contracts.py checks the wait in the built code.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1844,7 +1848,9 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
 // independent instructions of one class (mode 0: v_fma_f64 on 8 accumulators; mode 1: v_mov_b32).
 // bench.py times it with HIP events and prices the rollout kernel's per-step instruction mix
 // with the two intervals (roofline.issue_bound).
-__global__ void __launch_bounds__(kWave) issue_probe_kernel(int32_t trips, int32_t mode, double *out)
+// A grid of such waves (sw_issue_probe_grid: 256 workgroups x 4 waves = one wave on every SIMD) gives the
+// same intervals with the WHOLE chip issuing -- f64 on every SIMD lowers the clock the chip sustains.
+__global__ void __launch_bounds__(256) issue_probe_kernel(int32_t trips, int32_t mode, double *out)
 {
     double a0 = 1.0 + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,
            a6 = a0 + 6, a7 = a0 + 7;
@@ -1868,7 +1874,8 @@ __global__ void __launch_bounds__(kWave) issue_probe_kernel(int32_t trips, int32
     }
 #undef SW_FMA8
 #undef SW_MOV8
-    out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7);
+    // (every wave of a grid writes the same 64 doubles' worth of don't-care values)
+    out[threadIdx.x % kWave] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7);
 }
 
 // ---- dispatch on the segment count -------------------------------------------------
@@ -2038,6 +2045,19 @@ int sw_issue_probe(int32_t mode, int32_t trips, double *scratch64, void *stream)
     if (trips < 0 || (mode != 0 && mode != 1)) return SW_ERR_SIZE;
     hipLaunchKernelGGL(issue_probe_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, trips, mode,
                        scratch64);
+    return launch_status();
+}
+
+int sw_issue_probe_grid(int32_t mode, int32_t trips, int32_t workgroups, int32_t waves_per_workgroup,
+                        double *scratch64, void *stream)
+{
+    (void)hipGetLastError();
+    if (!scratch64) return SW_ERR_NULL;
+    if (trips < 0 || (mode != 0 && mode != 1) || workgroups < 1 || workgroups > 65536 ||
+        waves_per_workgroup < 1 || waves_per_workgroup > 4)
+        return SW_ERR_SIZE;
+    hipLaunchKernelGGL(issue_probe_kernel, dim3((unsigned)workgroups), dim3(kWave * waves_per_workgroup), 0,
+                       (hipStream_t)stream, trips, mode, scratch64);
     return launch_status();
 }
 
@@ -2359,6 +2379,7 @@ struct sw_env1 {
     double *io_host = nullptr, *io_dev = nullptr;   // SW_ENV1_DOUBLES doubles + {status, seq}
     hipStream_t stream = nullptr;
     uint32_t seq = 0;
+    int device = 0;   // the device that was current at sw_env1_create: every launch goes there
 };
 
 int sw_env1_create(sw_env1 **out)
@@ -2367,7 +2388,8 @@ int sw_env1_create(sw_env1 **out)
     sw_env1 *e = new (std::nothrow) sw_env1();
     if (!e) return SW_ERR_LAUNCH;
     const size_t bytes = sizeof(double) * SW_ENV1_DOUBLES + 64;
-    bool ok = hipHostMalloc((void **)&e->io_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    bool ok = hipGetDevice(&e->device) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->io_host, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) {
         memset(e->io_host, 0, bytes);
         ok = hipHostGetDevicePointer((void **)&e->io_dev, e->io_host, 0) == hipSuccess &&
@@ -2407,6 +2429,11 @@ static int env1_run(sw_env1 *e, const sw_params *p, bool accel, int32_t *status)
     const volatile uint32_t *flag_host = reinterpret_cast<const volatile uint32_t *>(st_host + 1);
     uint32_t *flag_dev = reinterpret_cast<uint32_t *>(st_dev + 1);
     const uint32_t seq = ++e->seq;
+    // the handle's stream and mapped block belong to e->device: launch there whatever the caller's current
+    // device is, and leave the caller's current device as it was
+    int caller_device = e->device;
+    if (hipGetDevice(&caller_device) != hipSuccess) return SW_ERR_LAUNCH;
+    if (caller_device != e->device && hipSetDevice(e->device) != hipSuccess) return SW_ERR_LAUNCH;
 #define SW_ENV1_LAUNCH(TW, AC)                                                                     \
     SW_DISPATCH_N(p->n, hipLaunchKernelGGL((env1_kernel<NN, TW, AC>), dim3(1), dim3(kWave), 0,     \
                                            e->stream, C, T, e->io_dev, st_dev, flag_dev, seq))
@@ -2417,6 +2444,7 @@ static int env1_run(sw_env1 *e, const sw_params *p, bool accel, int32_t *status)
     }
 #undef SW_ENV1_LAUNCH
     rc = launch_status();
+    if (caller_device != e->device) (void)hipSetDevice(caller_device);
     if (rc) return rc;
     for (int64_t spins = 0; *flag_host != seq; ++spins) {
         if ((spins & 0xffff) == 0xffff) {

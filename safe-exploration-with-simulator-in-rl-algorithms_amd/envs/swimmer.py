@@ -127,7 +127,6 @@ class SwimmerEnv(object):
         self.action_space = Box(-max_u, max_u, (n - 1,))
         self.device = torch.device(device)
         self._env1 = None   # kernels.SingleEnv, created on first use
-        self._dev_index = self.device.index or 0
 
     # parameters are plain attributes in the reference and may be reassigned between
     # calls (ars/estimator.py builds envs per candidate), so the struct is rebuilt lazily
@@ -143,10 +142,10 @@ class SwimmerEnv(object):
         """State and action into the handle's host-mapped I/O block (kernels.SingleEnv)."""
         require_gpu()
         if self._env1 is None:
-            with torch.cuda.device(self.device):   # the handle's stream lives on this device
+            # the handle binds to the device that is current at its creation and launches there ever after
+            # (sw_env1 keeps the device id; the caller's current device is never changed by a step)
+            with torch.cuda.device(self.device):
                 self._env1 = kernels.SingleEnv()
-        if torch.cuda.current_device() != self._dev_index:
-            torch.cuda.set_device(self._dev_index)
         a = np.asarray(torque, dtype=np.float64).reshape(-1)
         assert a.shape[0] == self.n - 1, f"Action {torque} has not the right dimension"
         io, d = self._env1.io, 2 * self.n + 2

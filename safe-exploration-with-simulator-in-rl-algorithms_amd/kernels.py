@@ -71,20 +71,37 @@ class StepPlan(object):
 class DirectComm(object):
     """sw_comm: the per-iteration all-gather issued straight into RCCL from native code on the
     current stream (no ProcessGroupNCCL in between).  COLLECTIVE constructor: rank 0 draws the
-    unique id, `broadcast_id(id_bytes_or_None)` must hand every rank rank 0's 128 bytes."""
+    unique id, `broadcast_id(id_bytes_or_None)` must hand every rank rank 0's 128 bytes, and
+    `agree(ok)` (a collective AND over the ranks; identity with one rank) makes a failure on ANY
+    rank -- RCCL not resolvable, the id not drawn, the communicator not created -- an exception
+    on EVERY rank instead of a hang of the others in the next collective.  The communicator binds
+    to the CURRENT device: construct it under `torch.cuda.device(...)`.  EXPERIMENTAL until it has
+    met more than one rank."""
 
-    def __init__(self, world, rank, broadcast_id):
+    def __init__(self, world, rank, broadcast_id, agree=None):
         require_gpu()
+        agree = agree or (lambda ok: ok)
         lib = load()
-        if not lib.sw_comm_available():
-            raise _lib.SwimmerHipError("RCCL (librccl.so.1) could not be resolved at run time")
+        why = None
         buf = (ctypes.c_uint8 * 128)()
-        if rank == 0:
-            check(lib.sw_comm_unique_id(buf), "sw_comm_unique_id")
+        if not lib.sw_comm_available():
+            why = "RCCL (librccl.so.1) could not be resolved at run time"
+        elif rank == 0:
+            rc = lib.sw_comm_unique_id(buf)
+            if rc:
+                why = f"sw_comm_unique_id: {_lib.ERR_NAMES.get(rc, rc)}"
+        if not agree(why is None):
+            raise _lib.SwimmerHipError("direct RCCL set-up failed on " +
+                                       (f"this rank: {why}" if why else "another rank"))
         ident = broadcast_id(bytes(buf) if rank == 0 else None)
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(ident)
         h = ctypes.c_void_p()
-        check(lib.sw_comm_create(ctypes.byref(h), buf, world, rank), "sw_comm_create")
+        rc = lib.sw_comm_create(ctypes.byref(h), buf, world, rank)
+        if not agree(rc == 0):
+            if rc == 0:
+                lib.sw_comm_destroy(h)
+            raise _lib.SwimmerHipError("sw_comm_create failed on " +
+                                       (f"this rank: {_lib.ERR_NAMES.get(rc, rc)}" if rc else "another rank"))
         self._h, self._lib, self.world, self.rank = h, lib, world, rank
         self._fn = lib.sw_comm_all_gather_f64
 
@@ -292,6 +309,34 @@ def issue_interval_ns(mode: int, device="cuda:0", trips: int = 8192):
         ns = (e1.elapsed_time(e2) - e0.elapsed_time(e1)) * 1e6 / (trips * 64)
         best = ns if best is None else min(best, ns)
     return best
+
+
+def issue_interval_full_chip_ns(mode: int, device="cuda:0", trips: int = 8192, workgroups: int = 256, waves: int = 4,
+                                settle_ms: float = 60.0):
+    """The same interval with a wave on EVERY SIMD (sw_issue_probe_grid, 256 workgroups x 4 waves): what an
+    instruction costs a wave once the whole chip issues -- f64 on every SIMD lowers the clock the chip
+    sustains, so the probe first loads the chip for `settle_ms` and then reports the MEDIAN of five
+    difference measurements (the lone-wave probe reports the best of three)."""
+    require_gpu()
+    scratch = torch.empty(64, dtype=torch.float64, device=device)
+    fn = load().sw_issue_probe_grid
+
+    def go(t):
+        check(fn(mode, t, workgroups, waves, ptr(scratch), stream_ptr()), "sw_issue_probe_grid")
+    per_launch_ms = trips * 64 * 2.3e-6
+    for _ in range(max(1, int(settle_ms / per_launch_ms))):
+        go(trips)
+    samples = []
+    for _ in range(5):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        go(trips)
+        e1.record()
+        go(2 * trips)
+        e2.record()
+        torch.cuda.synchronize()
+        samples.append((e1.elapsed_time(e2) - e0.elapsed_time(e1)) * 1e6 / (trips * 64))
+    return sorted(samples)[2]
 
 
 def cov_acc_doubles(p: SwParams, n_roll: int, H: int) -> int:

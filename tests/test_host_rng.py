@@ -32,6 +32,26 @@ def test_stream_is_bit_identical_to_numpy(seed):
         assert np.array_equal(r, g)
 
 
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_every_vector_width_gives_the_same_bits(level):
+    """The library is built on one machine and runs on another: baseline x86-64, AVX2 and AVX-512 builds of
+    the same loop are all in it, the CPU's features choose at run time (csrc/host_rng.cpp).  Each width the
+    CPU of this machine offers must reproduce NumPy's stream bit for bit."""
+    lib = sw._lib.load()
+    got = lib.sw_mt19937_force_isa(level)
+    try:
+        if got != level:
+            pytest.skip(f"this CPU runs width {got}, not {level}")
+        sizes = [3, 311, 313, 624, 625, 8191, 70001, 2]
+        np.random.seed(4321)
+        ref = [2 * np.random.rand(n) - 1 for n in sizes]
+        np.random.seed(4321)
+        for r, n in zip(ref, sizes):
+            assert np.array_equal(r, native_pm1(n))
+    finally:
+        lib.sw_mt19937_force_isa(-1)
+
+
 def test_interleaves_with_numpy_draws():
     np.random.seed(7)
     a1 = 2 * np.random.rand(100) - 1
