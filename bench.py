@@ -797,6 +797,8 @@ def summary(line, aux):
         "step4m_hbm_frac": r3(dig(aux, "step_only", "envs_4194304", "hbm_frac")),
         "sat262144_hbm_frac": r3(dig(aux, "rollout_saturated", "hbm_frac")),
         "sat65536_hbm_frac": r3(dig(aux, "rollout_saturated_65536", "hbm_frac")),
+        "sat_n6_hbm_frac": r3(dig(aux, "rollout_saturated_n6", "hbm_frac")),
+        "sat_n6_sps": r3(dig(aux, "rollout_saturated_n6", "env_steps_per_s")),
         "twin_step4m_hbm_frac": r3(dig(aux, "next_rows", "twin_step_envs_4194304", "hbm_frac")),
         "coll1_us": r3(dig(aux, "collective_one_rank", "collective_us")),
         "coll1_ms": r3(dig(aux, "collective_one_rank", "ms_per_iteration")),
@@ -1007,13 +1009,17 @@ def run_rank(args):
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)
             aux["rollout_saturated_65536"] = guarded(aux_rollout_saturated, sw, torch, device, n_roll=65536)
+            # the six-segment chain in the same regime (configs[4]'s swimmer, one rollout per lane, 112 B per env-step;
+            # H = 500 keeps the buffer at 3.7 GB): where the lane kernel's O(n^2 .. n^3) step stands against HBM
+            aux["rollout_saturated_n6"] = guarded(aux_rollout_saturated, sw, torch, device, n=6, n_roll=65536,
+                                                  H=500, reps=9)
         if not args.no_aux and world == 1:
             aux["single_env"] = guarded(aux_single_env, sw, torch, device)
         if aux:
             line["aux"] = aux
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = guarded(cpu_baseline, n, H, args.directions, args.cpu_seconds)
-        # LAST key, flat and short (< 1500 characters): every config's number survives a record
+        # LAST key, flat and short (< 1900 characters): every config's number survives a record
         # that keeps only the tail of the line and only scalar members of its objects
         line["summary"] = summary(line, aux)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,155 @@
+"""safe_ars/ars.py of the reference, batched: `Basic_ARS` (:9-98) and `Safe_ARS` (:101-153).
+
+The reference runs its 2N rollouts one after the other, and inside a `Safe_ARS` rollout every real step is
+gated by a ONE-STEP look-ahead in a simulator: `isSafe` = `sim_env.set_state(obs)` + `sim_env.step(action)` +
+`cost(sim obs) <= sim_thresh` (:111-122, called at :141).  That look-ahead is exactly the batched
+set_state + step surface of the step kernel (SURVEY 8f-1's third consumer), so here ALL rollouts advance in lock
+step: per step two launches of `sw_step_f64` over the whole batch (simulator parameters, real parameters, the same
+states and actions) and the gate as a mask -- a refused swimmer keeps its state (:150-151), which makes it propose
+the same action again, so it stays refused for the rest of the horizon, as in the reference.
+
+Same class names, constructor arguments, method names and return types as the reference; `rollouts` (plural) is
+the batched form the other methods are built on.  `real_env` / `sim_env` are `SwimmerEnv` objects (only their
+physical parameters are used: every rollout starts from `reset()`, :125).  `cost` is the reference's callable on
+an observation; it is evaluated ONCE per step on the whole batch as a [d, B] tensor -- `abs(obs[3])` works
+unchanged -- and falls back to one call per swimmer for callables that cannot take tensors.
+No CPU fallback for the physics: every step goes through the C ABI.
+"""
+import numpy as np
+import torch
+
+from .. import kernels
+from .._lib import SwParams, numpy_global_uniform_pm1, require_gpu
+
+
+def _params(env):
+    return SwParams.make(env.n, env.l_i, env.m_i, env.k, env.h, env.direction)
+
+
+class Basic_ARS(object):
+    """safe_ars/ars.py:9-98 -- ARS with true top-b truncation (`order[:b]`, :96) and the divisor len(order) (:64)."""
+
+    def _gate(self, sim_next, state, action):      # Basic_ARS: every step is taken
+        return None
+
+    def rollouts(self, real_env, policies, H):
+        """B rollouts of H steps in lock step.  policies: [B, m, d].  Returns (returns [B], states [B, H, d]) as
+        NumPy arrays; states[b, t] is the observation after step t (the unchanged one where step t was refused)."""
+        require_gpu()
+        dev = getattr(real_env, "device", torch.device("cuda:0"))
+        p_real = _params(real_env)
+        P = torch.as_tensor(np.ascontiguousarray(policies, dtype=np.float64), device=dev)
+        B, m, d = P.shape
+        assert (m, d) == (p_real.m, p_real.d), f"policies must be [B, {p_real.m}, {p_real.d}]"
+        state = kernels.reset(p_real, B, dev)
+        nxt = torch.empty_like(state)
+        rew = torch.empty(B, dtype=torch.float64, device=dev)
+        total = torch.zeros(B, dtype=torch.float64, device=dev)
+        states = torch.empty((H, d, B), dtype=torch.float64, device=dev)
+        self._prepare(B, d, dev)
+        for t in range(H):
+            action = torch.einsum("bmd,db->mb", P, state).contiguous()     # ac = policy @ obs (:139)
+            safe = self._gate(state, action)
+            kernels.step(p_real, state, action, out=nxt, reward=rew)
+            if safe is None:
+                state, nxt = nxt, state
+                total += rew
+            else:
+                self._after_real_step(nxt, safe)
+                state = torch.where(safe, nxt, state)                       # refused: stay (:150-151)
+                total += torch.where(safe, rew, torch.zeros_like(rew))
+            states[t] = state
+        return total.cpu().numpy(), states.permute(2, 0, 1).cpu().numpy()
+
+    def _prepare(self, B, d, dev):
+        pass
+
+    def _after_real_step(self, nxt, safe):
+        pass
+
+    def rollout(self, real_env, policy, H, render=False):
+        """One rollout, with the reference's return types: (float, list of H observation lists)."""
+        R, st = self.rollouts(real_env, np.asarray(policy, dtype=np.float64)[None], H)
+        return float(R[0]), st[0].tolist()
+
+    def sort_directions(self, deltas, rewards):
+        max_rewards = [max(rewards[2 * i], rewards[2 * i + 1]) for i in range(len(deltas))]
+        return np.argsort(max_rewards).tolist()[::-1]
+
+    def update_policy(self, deltas, returns, order, alpha):
+        used = []
+        for i in order:
+            used += [returns[2 * i], returns[2 * i + 1]]
+        sigma_r = np.std(used)
+        grad = np.zeros(self.policy.shape)
+        for i in order:
+            grad += (returns[2 * i] - returns[2 * i + 1]) * deltas[i]
+        grad /= (len(order) * sigma_r)
+        self.policy += alpha * grad
+
+    def train(self, n_iter, real_env, N, b, alpha, nu, H):
+        """safe_ars/ars.py:67-98 with the 2N rollouts of an iteration as ONE lock-step batch.  The noise comes
+        from NumPy's global generator in the reference's order (N draws of 2 * rand(m, d) - 1, :84)."""
+        n_obs = real_env.observation_space.shape[0]
+        n_ac = real_env.action_space.shape[0]
+        self.policy = np.zeros((n_ac, n_obs))
+        all_returns, states = [], []
+        deltas = np.empty((N, n_ac, n_obs))
+        for it in range(n_iter):
+            numpy_global_uniform_pm1(deltas)
+            pols = np.empty((2 * N, n_ac, n_obs))
+            pols[0::2] = self.policy + nu * deltas
+            pols[1::2] = self.policy - nu * deltas
+            returns, st = self.rollouts(real_env, pols, H)
+            returns = returns.tolist()
+            states.extend(st)
+            order = self.sort_directions(deltas, returns)
+            self.update_policy(deltas, returns, order[:b], alpha)
+            all_returns.append(np.mean(returns))
+            if it % 10 == 0:
+                print(f"Iteration {it}/{n_iter}: return = {all_returns[-1]}")
+        return np.array(all_returns), np.array(states)
+
+
+class Safe_ARS(Basic_ARS):
+    """safe_ars/ars.py:101-153 -- every real step gated by a one-step look-ahead in `sim_env`."""
+
+    def __init__(self, cost, real_threshold, sim_threshold, sim_env):
+        self.cost = cost
+        self.real_thresh = real_threshold
+        self.sim_thresh = sim_threshold
+        self.sim_env = sim_env
+        self.real_violations = 0      # real steps whose cost exceeded real_thresh (the reference prints each, :143-144)
+
+    def _prepare(self, B, d, dev):
+        self._p_sim = _params(self.sim_env)
+        self._sim_next = torch.empty((d, B), dtype=torch.float64, device=dev)
+
+    def _cost_batch(self, obs):
+        """cost over a [d, B] batch -> [B] tensor (one tensor call; per-swimmer calls if the callable refuses)."""
+        B = obs.shape[1]
+        try:
+            c = self.cost(obs)
+            c = torch.as_tensor(c, dtype=torch.float64, device=obs.device)
+            if c.shape == (B,):
+                return c
+        except Exception:   # noqa: BLE001 -- a cost written for Python lists only
+            pass
+        rows = obs.T.cpu().numpy().tolist()
+        return torch.as_tensor([float(self.cost(r)) for r in rows], dtype=torch.float64, device=obs.device)
+
+    def isSafe(self, cost, thresh, env, state, action):
+        """The reference's single-swimmer form (:111-122), through the drop-in env."""
+        env.set_state(state)
+        obs, _, _, _ = env.step(action)
+        return cost(obs) <= thresh
+
+    def _gate(self, state, action):
+        kernels.step(self._p_sim, state, action, out=self._sim_next)       # set_state(obs) + step(ac) for all B
+        return self._cost_batch(self._sim_next) <= self.sim_thresh
+
+    def _after_real_step(self, nxt, safe):
+        over = (self._cost_batch(nxt) > self.real_thresh) & safe
+        n_over = int(over.sum().item())
+        if n_over:
+            self.real_violations += n_over

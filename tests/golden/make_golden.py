@@ -528,11 +528,69 @@ def gen_next_rows():
     print("next_rows.npz", len(out), "I", out["est_I"], "J", out["est_J"])
 
 
+def gen_safe_ars():
+    """Round 4: the third batched one-step consumer SURVEY 8f-1 cites -- safe_ars/ars.py Safe_ARS (:101-153):
+    `isSafe` = sim_env.set_state(obs) + sim_env.step(action) + cost(sim obs) <= sim_thresh gates EVERY real
+    step (:111-122, :141); a refused step leaves the real env where it is (:150-151), so the same action is
+    proposed -- and refused -- for the rest of the horizon.  Cost = |thetadot_1| (obs[3]); the simulator is the
+    default-parameter swimmer, the real env the "realworld" one.  (a) single rollouts of fixed policies, some
+    refused at different steps, some never; (b) Safe_ARS.train (inherited from Basic_ARS, :67-98, with the gated
+    rollout) for n_iter = 1, 2, 3 from one seed."""
+    out = {}
+    arsmod = _load_by_path("ref_safe_ars", "safe_ars/ars.py")
+
+    def cost(obs):
+        return abs(obs[3])
+
+    n, H, sim_thresh, real_thresh = 3, 80, 0.30, 0.33
+    out["cfg"] = np.array([n, H], dtype=np.int64)
+    out["thresholds"] = np.array([sim_thresh, real_thresh])
+    out["real_phys"] = np.array(PARAM_SETS["realworld"])
+    out["sim_phys"] = np.array(PARAM_SETS["default"])
+    rs = np.random.RandomState(77)
+    pols = np.stack([sc * (2 * rs.rand(n - 1, 2 * n + 2) - 1) for sc in (0.05, 0.3, 0.6, 1.0, 1.5, 2.5, 0.8, 1.2)])
+    agent = arsmod.Safe_ARS(cost, real_thresh, sim_thresh, make_env(n, "default"))
+    R = np.empty(len(pols))
+    states = np.empty((len(pols), H, 2 * n + 2))
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i, P in enumerate(pols):
+            R[i], st = agent.rollout(make_env(n, "realworld"), P, H)
+            states[i] = np.array(st)
+    out["rollout_policies"] = pols
+    out["rollout_returns"] = R
+    out["rollout_states"] = states
+    # first refused step of each rollout (H = never): from then on the state repeats
+    same = np.all(states[:, 1:] == states[:, :-1], axis=2)
+    first = np.array([int(np.argmax(s)) + 1 if s.any() else H for s in same])
+    out["rollout_first_refused"] = first
+    print("safe_ars: first refused step per policy", first.tolist(), "returns", R)
+
+    N, b, Ht, alpha, nu, seed, iters = 6, 3, 60, 0.02, 0.9, 11, 3
+    tp = np.empty((iters, n - 1, 2 * n + 2))
+    curves = []
+    for k in range(1, iters + 1):
+        agent = arsmod.Safe_ARS(cost, real_thresh, sim_thresh, make_env(n, "default"))
+        np.random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            curve, st = agent.train(k, make_env(n, "realworld"), N, b, alpha, nu, Ht)
+        tp[k - 1] = agent.policy
+        curves.append(curve)
+    assert all(np.array_equal(curves[-1][:len(c)], c) for c in curves)
+    out["train_cfg"] = np.array([N, b, Ht, seed, iters], dtype=np.int64)
+    out["train_hyper"] = np.array([alpha, nu])
+    out["train_policies"] = tp
+    out["train_curve"] = np.array(curves[-1])
+    out["train_last_states"] = np.array(st[-2 * N:])       # the last iteration's 2N rollouts [2N, Ht, d]
+    np.savez_compressed(os.path.join(OUT, "safe_ars.npz"), **out)
+    print("safe_ars.npz", len(out), "curve", out["train_curve"])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # e.g. `make_golden.py mirrors long`: only these files
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
         sys.exit(0)
+    gen_safe_ars()
     gen_next_rows()
     gen_mirrors()
     gen_long()

@@ -10,12 +10,16 @@ from conftest import ROOT
 def test_summary_is_flat_short_and_last():
     shard = {"ms_per_iteration": 0.5123456, "env_steps_per_s": 1.23456789e9,
              "roofline": {"kernel_ms": 0.50123, "frac": 0.014321,
-                          "issue_bound": {"frac": 0.93123, "measured_over_priced": 1.3061}}}
+                          "issue_bound": {"frac": 0.93123, "measured_over_priced": 1.3061,
+                                          "measured_over_priced_full_chip": 1.1683}}}
     aux = {k: shard for k in ("shard_n3_256_directions", "shard_n6_256_directions",
                               "ars_2048_directions_one_gpu", "ars_2048_directions_one_gpu_n6")}
     aux.update(step_only={"envs_8192": {"us_per_launch": 3.2123, "env_steps_per_s": 2.5e9},
                           "envs_4194304": {"hbm_frac": 0.6912}},
                rollout_saturated={"hbm_frac": 0.6171}, rollout_saturated_65536={"hbm_frac": 0.7172},
+               rollout_saturated_n6={"hbm_frac": 0.3121, "env_steps_per_s": 2.2312e10},
+               host_cost_at_8_ranks={k: {"host_us_per_iteration": 170.65, "host_bound": False}
+                                     for k in ("n3_4096_directions", "n6_2048_directions", "n6_4096_directions")},
                next_rows={"twin_step_envs_4194304": {"hbm_frac": 0.683},
                           "estimator_objective": {"us_per_evaluation": 127.04},
                           "ars_v1_iteration": {"ms_per_iteration": 0.2301},
@@ -30,10 +34,11 @@ def test_summary_is_flat_short_and_last():
             "cpu_baseline": {"value": 5.22e7, "cores": 16}}
     sm = bench.summary(line, aux)
     assert all(isinstance(v, (int, float, bool)) for v in sm.values())      # scalars only
-    assert len(json.dumps(sm)) < 1500
+    assert len(json.dumps(sm)) < 1900          # the driver's record keeps the last 2000 characters of stdout
     for key in ("n6_sh256_ms", "n6_sh256_sps", "n6_sh256_hbm_frac", "n6_sh256_issue_frac", "n3_sh256_ms",
                 "n3_2048_1gpu_ms", "n6_2048_1gpu_over_priced", "step8192_us", "step4m_hbm_frac",
-                "sat262144_hbm_frac", "sat65536_hbm_frac", "coll1_us", "gym_step_us", "rlglue_step_us"):
+                "sat262144_hbm_frac", "sat65536_hbm_frac", "coll1_us", "gym_step_us", "rlglue_step_us",
+                "n6_2048_1gpu_over_priced_full_chip", "sat_n6_hbm_frac", "host_us_n6_4096", "host_bound_n6_4096"):
         assert key in sm
     assert sm["n3_ms"] == 0.2602 and "n_gpus" not in sm                   # main leg: n = 3 unless the config says otherwise
     multi = dict(line, n_gpus=8, config={"segments": 6})

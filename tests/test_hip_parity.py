@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import PARAM_SETS
+from conftest import observed, PARAM_SETS
 
 pytestmark = pytest.mark.gpu
 
@@ -78,11 +78,9 @@ def test_config2_8192_envs_vs_oracle(sw):
         print(f"config2 {pset}: {report[pset]}")
         assert err <= STEP_TOL
         assert np.abs(rew.cpu().numpy() - ref_rew).max() <= STEP_TOL
-    # SWIMMER_REPORT_DIR=<dir>: keep the figures (profiles/ holds a copy of the last run)
-    out = os.environ.get("SWIMMER_REPORT_DIR")
-    if out:
-        with open(os.path.join(out, "config2_bitmatch.json"), "w") as f:
-            json.dump(report, f, indent=1)
+    # north_star says "bit-match vs CPU" for this config; what is delivered is <= 1 ulp on ~99 % of the doubles
+    # (the device solves the reduced n x n system with its own sin / cos): the fractions are kept with the run
+    observed("config2_bitmatch", report)
 
 
 def test_known_answers(sw, golden):
@@ -379,7 +377,25 @@ def test_fast_spinning_segments_stay_exact(sw, n, kernel):
     # (relative) from the oracle after 120 such steps; a sin / cos evaluated one step's travel
     # outside its range would be off by 1e-3 and more
     scale = np.maximum(1.0, np.abs(ref))
-    assert (np.abs(got - ref) / scale).max() <= 1e-6           # contract: 1e-5
+    rel = (np.abs(got - ref) / scale).max()
+    # The contract's tolerance is ABSOLUTE (1e-5).  It can only be asked for where the reference itself is still
+    # well conditioned: these are chaotic states, a perturbation of the START state by 1e-13 (relative) moves the
+    # oracle's own trajectory by up to ... (printed below).  So: run the oracle a second time from such a start
+    # state; every (rollout, step) whose state the perturbation moved by less than 1e-8 -- an amplification below
+    # 1e5 -- must agree with the oracle to 1e-5 ABSOLUTE (observed: orders of magnitude better); beyond that the
+    # relative bound above is all that can be asked of any implementation.
+    ref2 = np.stack([oracle.rollout(op, H, pol[r], state0=st0[r] * (1.0 + 1e-13))[1] for r in range(R)])
+    moved = np.abs(ref2 - ref).max(axis=2)                       # [R, H]
+    tame = moved < 1e-8
+    abs_err = np.abs(got - ref).max(axis=2)
+    observed(f"fast_spinning_n{n}_{kernel}", {
+        "max_relative_error": float(rel), "max_absolute_error_all_steps": float(abs_err.max()),
+        "max_absolute_error_well_conditioned_steps": float(abs_err[tame].max()),
+        "well_conditioned_fraction": float(tame.mean()),
+        "oracle_moved_by_1e-13_start_perturbation_max": float(moved.max())})
+    assert rel <= 1e-6                                           # everywhere (relative to max(1, |ref|))
+    assert tame.mean() >= 0.25                                   # the absolute check is not vacuous
+    assert abs_err[tame].max() <= 1e-5                           # the contract's absolute tolerance
 
 
 def test_edge_cases(sw):
@@ -738,3 +754,63 @@ def test_physical_invariants_at_scale(sw, n):
     gx = c * gdd1[0] - s_ * gdd1[1]
     gy = s_ * gdd1[0] + c * gdd1[1]
     assert float(torch.maximum((gdd_r[0] - gx).abs(), (gdd_r[1] - gy).abs()).max()) <= 1e-12 * max(1.0, float(gdd1.abs().max()))
+
+
+def test_safe_ars_gate_vs_reference(sw, golden):
+    """SURVEY 8f-1's third consumer: safe_ars/ars.py Safe_ARS (:101-153) as the REFERENCE ran it
+    (tests/golden/safe_ars.npz, cost = |thetadot_1|, simulator = default swimmer, real env = "realworld").  Here
+    all rollouts advance in lock step: per step the simulator look-ahead (`isSafe` = set_state + step + cost, :111-122)
+    and the real step are two launches of the step kernel over the batch, the gate is a mask.  The gate must close
+    at the reference's step for every rollout (5 ... 32, and never), states / returns / trained policies agree."""
+    g = golden.safe_ars
+    n, H = (int(v) for v in g["cfg"])
+    sim_thresh, real_thresh = (float(v) for v in g["thresholds"])
+    l, m, k, h = (float(v) for v in g["real_phys"])
+    real = sw.SwimmerEnv(n=n, l_i=l, m_i=m, k=k, h=h)
+    l, m, k, h = (float(v) for v in g["sim_phys"])
+    sim = sw.SwimmerEnv(n=n, l_i=l, m_i=m, k=k, h=h)
+    cost = lambda obs: abs(obs[3])      # noqa: E731 -- works on an observation list and on a [d, B] tensor
+    agent = sw.safe_ars.Safe_ARS(cost, real_thresh, sim_thresh, sim)
+    R, st = agent.rollouts(real, g["rollout_policies"], H)          # the eight rollouts as ONE batch
+    assert np.abs(st - g["rollout_states"]).max() <= 1e-10
+    assert np.abs(R - g["rollout_returns"]).max() <= 1e-12
+    same = np.all(st[:, 1:] == st[:, :-1], axis=2)
+    firsts = [int(np.argmax(s)) + 1 if s.any() else H for s in same]
+    assert firsts == g["rollout_first_refused"].tolist()
+    # the single-rollout form with the reference's return types, and its own isSafe through the drop-in env
+    r0, s0 = agent.rollout(real, g["rollout_policies"][3], H)
+    assert isinstance(r0, float) and isinstance(s0, list) and len(s0) == H and isinstance(s0[0], list)
+    assert np.abs(np.array(s0) - g["rollout_states"][3]).max() <= 1e-10
+    obs0 = real.reset()
+    assert agent.isSafe(cost, sim_thresh, sim, obs0, g["rollout_policies"][0] @ np.array(obs0)) in (True, np.True_)
+    # a cost written for Python lists only (math.fabs refuses tensors): per-swimmer fallback, same result
+    import math
+    agent2 = sw.safe_ars.Safe_ARS(lambda obs: math.fabs(obs[3]), real_thresh, sim_thresh, sim)
+    R2, st2 = agent2.rollouts(real, g["rollout_policies"], H)
+    assert np.array_equal(st2, st) and np.array_equal(R2, R)
+    # training: three iterations from the reference's seed
+    N, b, Ht, seed, iters = (int(v) for v in g["train_cfg"])
+    alpha, nu = (float(v) for v in g["train_hyper"])
+    for kk in range(1, iters + 1):
+        np.random.seed(seed)
+        a = sw.safe_ars.Safe_ARS(cost, real_thresh, sim_thresh, sim)
+        curve, states = a.train(kk, real, N, b, alpha, nu, Ht)
+        assert np.abs(a.policy - g["train_policies"][kk - 1]).max() <= 1e-9
+        assert np.abs(curve - g["train_curve"][:kk]).max() <= 1e-12
+    assert states.shape == (2 * N * iters, Ht, 2 * n + 2)
+    assert np.abs(states[-2 * N:] - g["train_last_states"]).max() <= 1e-9
+
+
+def test_basic_ars_mirror_vs_reference(sw, golden):
+    """safe_ars.Basic_ARS (the ungated parent class): `train` against the reference's Basic_ARS.train goldens."""
+    g = golden.next_rows
+    tag = "basic_n3_N8_b3"
+    n, N, b, H, seed, iters = (int(v) for v in g[tag + "_cfg"])
+    l, m, k, h, alpha, nu = (float(v) for v in g[tag + "_phys"])
+    env = sw.SwimmerEnv(n=n, l_i=l, m_i=m, k=k, h=h)
+    np.random.seed(seed)
+    a = sw.safe_ars.Basic_ARS()
+    curve, states = a.train(iters, env, N, b, alpha, nu, H)
+    assert np.abs(a.policy - g[tag + "_policies"][iters - 1]).max() <= 1e-9
+    assert np.abs(curve - g[tag + "_curve"]).max() <= 1e-12 * max(1.0, np.abs(g[tag + "_curve"]).max())
+    assert np.abs(states[-1][-1] - g[tag + "_last_state"]).max() <= 1e-9

@@ -5,7 +5,12 @@ earlier in the file.  This test reads the offsets out of the built library and c
 the sweep on the GPU chose (profiles/r03_p_loop_pad_sweep_*.log, r03_q_final_pads.log).  If it fails after
 a change to a kernel (or a new compiler), the loop has moved relative to its pin: run the sweep again
 (scripts/ab_probe.sh over builds with -DSW_OCT_LOOP_PAD=k -DSW_QUAD_LOOP_PAD=k -DSW_ROW_LOOP_PAD=k) and
-update the pads and this table."""
+update the pads and this table.
+
+A PERF LINT, not a correctness test (marker `perf_lint`: deselect with -m "not perf_lint"): the table belongs to
+ONE compiler build (PINNED_COMPILER) -- under any other hipcc the test skips, because its offsets mean nothing
+there -- and a failure lists every loop's new (bytes, offset), so updating the table after a deliberate kernel
+change is mechanical."""
 import os
 import re
 import shutil
@@ -16,6 +21,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "safe-exploration-with-simulator-in-rl-algorithms_amd", "csrc", "libswimmer_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
+
+PINNED_COMPILER = "roc-7.2.0 26014"      # `hipcc --version`: the build the sweep's offsets belong to
 
 # kernel (mangled-name fragment) -> (bytes of the hot loop's body, offset of its head inside a 64-byte line)
 EXPECTED = {
@@ -60,12 +67,31 @@ def _backward_loops(lines, fragment):
     return out
 
 
+def _compiler():
+    try:
+        return subprocess.run([shutil.which("hipcc") or "/opt/rocm/bin/hipcc", "--version"], capture_output=True,
+                              text=True, timeout=60).stdout
+    except OSError:
+        return ""
+
+
+@pytest.mark.perf_lint
 @pytest.mark.skipif(not (os.path.exists(LIB) and shutil.which(f"{LLVM}/llvm-objdump")),
                     reason="needs the built library and the ROCm llvm tools")
 def test_hot_loops_sit_where_the_sweep_put_them(tmp_path):
+    if PINNED_COMPILER not in _compiler():
+        pytest.skip(f"the placement table belongs to hipcc {PINNED_COMPILER}; another compiler lays the loops out anew")
     lines = _disassemble(tmp_path)
+    moved = []
     for fragment, (body, where) in EXPECTED.items():
-        loops = [(h, b) for h, b, op in _backward_loops(lines, fragment) if b == body and op == "s_cbranch_scc0"]
-        assert len(loops) == 1, (fragment, "hot loop of", body, "bytes not found: the kernel's code changed", loops)
-        head = loops[0][0]
-        assert head % 64 == where, (fragment, "hot loop head at", head % 64, "of its 64-byte line, the sweep chose", where)
+        all_loops = _backward_loops(lines, fragment)
+        loops = [(h, b) for h, b, op in all_loops if b == body and op == "s_cbranch_scc0"]
+        if len(loops) != 1:
+            biggest = max(all_loops, key=lambda t: t[1], default=None)
+            moved.append(f"{fragment}: no hot loop of {body} bytes any more (the kernel's code changed); largest "
+                         f"backward loop now: {biggest and (biggest[1], biggest[0] % 64)}")
+        elif loops[0][0] % 64 != where:
+            moved.append(f"{fragment}: hot loop ({body} bytes) at offset {loops[0][0] % 64} of its 64-byte line, "
+                         f"the sweep chose {where}")
+    assert not moved, ("loops moved relative to their pins -- re-run the pad sweep and update EXPECTED "
+                       "(new (bytes, offset) listed):\n  " + "\n  ".join(moved))

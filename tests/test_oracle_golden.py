@@ -203,3 +203,29 @@ def test_estimator_objectives_vs_reference(golden):
         else:
             assert got_I == pytest.approx(want_I, rel=1e-11)
             assert got_J == pytest.approx(want_J, rel=1e-11)
+
+
+# ---- round 4: the safe-exploration gate (safe_ars/ars.py Safe_ARS), tests/golden/safe_ars.npz ----
+def test_safe_ars_oracle_vs_reference(golden):
+    """oracle/safe_ars_oracle.py against what the reference's Safe_ARS.rollout / Safe_ARS.train returned: rollouts
+    refused by the simulator look-ahead at steps 5 ... 32 and one that is never refused; three training iterations."""
+    from oracle import safe_ars_oracle as sao
+    g = golden.safe_ars
+    n, H = (int(v) for v in g["cfg"])
+    sim_thresh, real_thresh = (float(v) for v in g["thresholds"])
+    p_real = oracle.OracleParams.make(n, *[float(v) for v in g["real_phys"]])
+    p_sim = oracle.OracleParams.make(n, *[float(v) for v in g["sim_phys"]])
+    cost = lambda obs: abs(obs[3])      # noqa: E731 -- |thetadot_1|, the generator's cost
+    firsts = []
+    for P, R_ref, st_ref in zip(g["rollout_policies"], g["rollout_returns"], g["rollout_states"]):
+        R, st = sao.safe_rollout(p_real, p_sim, cost, sim_thresh, P, H)
+        assert np.abs(st - st_ref).max() <= 1e-12 and abs(R - R_ref) <= 1e-13
+        same = np.all(st[1:] == st[:-1], axis=1)
+        firsts.append(int(np.argmax(same)) + 1 if same.any() else H)
+    assert firsts == g["rollout_first_refused"].tolist()          # the gate closes at the reference's steps
+    assert len(set(firsts)) >= 5 and H in firsts                  # the fixture exercises the gate
+    N, b, Ht, seed, iters = (int(v) for v in g["train_cfg"])
+    alpha, nu = (float(v) for v in g["train_hyper"])
+    pols, curve = sao.safe_train(p_real, p_sim, cost, sim_thresh, iters, N, b, alpha, nu, Ht, seed)
+    assert np.abs(pols - g["train_policies"]).max() <= 1e-9
+    assert np.abs(curve - g["train_curve"]).max() <= 1e-12
