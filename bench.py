@@ -203,7 +203,7 @@ def pmc_traffic(kernel, n, directions, H):
     kernel sources than the ones this run was built from."""
     if (n, directions, H) != (3, 512, 1000):
         return None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_j_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_j_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             doc = json.load(open(path))

@@ -1525,7 +1525,12 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
     // registers this kernel does not have at n >= 6): a trip whose angles move at most kTripSlack runs
     // unchecked after one re-normalisation at its start if needed -- r ends at most that far past pi/4,
     // where the polynomials are still accurate to 2.5e-16 (swimmer_oct3.h); a faster trip runs in the
-    // second loop, which checks inside every step (exact for any angular velocity).  One step per loop
+    // second loop, which checks inside every step (exact for any angular velocity).  What thetadot GAINS inside
+    // an unchecked trip is not in that bound: an angle travels up to 6 h^2 |thetadotdot| further (0.06 rad at
+    // 10 000 rad/s^2) before the next trip start sees the speed.  The polynomials degrade smoothly out there --
+    // 2.0e-16 at pi/4 + 0.04, 1.7e-15 at + 0.10, 9e-14 at + 0.25 (tests/test_trig_range.py) -- and rollouts with
+    // first-step accelerations of 3 000 ... 20 000 rad/s^2 stay within 1e-6 (relative) of the oracle
+    // (tests/test_hip_parity.py::test_violent_accelerations_inside_an_unchecked_trip).  One step per loop
     // body either way: unrolled, n >= 6 would leave the 256 architectural registers.
     auto too_fast = [&]() -> bool {
         return __any((4.0 * C.h) * fabs(thd) > sw::kTripSlack);

@@ -29,7 +29,7 @@ def _params(env):
 class Basic_ARS(object):
     """safe_ars/ars.py:9-98 -- ARS with true top-b truncation (`order[:b]`, :96) and the divisor len(order) (:64)."""
 
-    def _gate(self, sim_next, state, action):      # Basic_ARS: every step is taken
+    def _gate(self, state, action):      # Basic_ARS: every step is taken
         return None
 
     def rollouts(self, real_env, policies, H):

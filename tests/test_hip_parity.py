@@ -814,3 +814,49 @@ def test_basic_ars_mirror_vs_reference(sw, golden):
     assert np.abs(a.policy - g[tag + "_policies"][iters - 1]).max() <= 1e-9
     assert np.abs(curve - g[tag + "_curve"]).max() <= 1e-12 * max(1.0, np.abs(g[tag + "_curve"]).max())
     assert np.abs(states[-1][-1] - g[tag + "_last_state"]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("n", [4, 6, 7, 8])
+def test_violent_accelerations_inside_an_unchecked_trip(sw, n):
+    """The row kernel (n = 4 ... 8) checks its reduced angles once per trip of FOUR steps, from |thetadot| at the
+    trip's START (csrc/swimmer_kernels.hip, `too_fast`): what thetadot GAINS inside the trip is not in that bound
+    (ADVICE r03).  Worst case for it: rollouts that start at rest (thetadot = 0: every first trip runs unchecked)
+    under policies whose gains of 20 ... 100 produce joint torques of hundreds, i.e. angular accelerations of
+    thousands of rad/s^2 -- an angle then travels 6 h^2 thetadotdot = 0.01 ... 0.1 rad inside ONE unchecked trip, up
+    to twice the 0.04 rad the polynomials were verified for, before the next trip start sees the speed and switches
+    to the per-step check.  The minimax polynomials degrade gracefully there (2.5e-16 at pi/4 + 0.04, ~1e-15 at
+    pi/4 + 0.1; tests/test_trig_range.py), so the kernel must still agree with the oracle: relative 1e-6 everywhere,
+    1e-5 absolute (the contract) wherever the reference itself is well conditioned."""
+    rs = np.random.RandomState(100 + n)
+    R, H, d, m = 32, 24, 2 * n + 2, n - 1
+    gains = np.repeat([20.0, 40.0, 70.0, 100.0], R // 4)
+    pol = gains[:, None, None] * (2 * rs.rand(R, m, d) - 1)
+    op = oracle.OracleParams.make(n)
+    ref = np.stack([oracle.rollout(op, H, pol[r])[1] for r in range(R)])          # from reset: theta = pi/2, at rest
+    ref2 = np.stack([oracle.rollout(op, H, pol[r] * (1.0 + 1e-13))[1] for r in range(R)])
+    p = sw.SwParams.make(n, flags=sw._lib.kernel_flags("quad"))
+    traj = torch.empty((H, d, R), dtype=torch.float64, device="cuda:0")
+    status = torch.zeros(R, dtype=torch.int32, device="cuda:0")
+    sw.kernels.rollout(p, H, torch.as_tensor(pol, device="cuda:0"), traj=traj, status=status)
+    got = traj.permute(2, 0, 1).cpu().numpy()
+    # explicit Euler under such gains blows up after a few dozen steps (in the reference too): compare every rollout
+    # up to the step before its state leaves 1e6, and ask that the comparison still covers the first trips everywhere
+    sane = np.logical_and.accumulate(np.isfinite(ref).all(axis=2) & (np.abs(ref).max(axis=2) < 1e6), axis=1)   # [R, H]
+    assert sane[:, :8].all() and sane.mean() >= 0.4
+    fin = sane[:, 0]
+    # angular accelerations reached (first step: thetadot_1 / h)
+    acc0 = np.abs(ref[:, 0, 3::2]).max(axis=1) / 1e-3
+    safe_ref = np.where(sane[:, :, None], ref, 0.0)
+    rel = (np.where(sane[:, :, None], np.abs(got - safe_ref), 0.0) / np.maximum(1.0, np.abs(safe_ref))).max()
+    moved = np.where(sane, np.abs(np.where(sane[:, :, None], ref2 - ref, 0.0)).max(axis=2), np.inf)
+    tame = (moved < 1e-8) & sane
+    abs_err = np.where(sane, np.abs(np.where(sane[:, :, None], got - ref, 0.0)).max(axis=2), 0.0)
+    observed(f"violent_trips_n{n}", {"max_first_step_angular_acceleration": float(acc0.max()),
+                                     "travel_inside_first_trip_rad": float(6e-6 * acc0.max()),
+                                     "max_relative_error": float(rel),
+                                     "max_absolute_error_well_conditioned_steps": float(abs_err[tame].max()),
+                                     "well_conditioned_fraction": float(tame.mean()),
+                                     "compared_fraction": float(sane.mean())})
+    assert acc0.max() > 3000.0                 # the in-trip gain really exceeds what `too_fast` allows for
+    assert rel <= 1e-6
+    assert abs_err[tame].max() <= 1e-5
