@@ -813,7 +813,7 @@ def summary(line, aux):
         "gym_step_us": r3(dig(aux, "single_env", "gym_step_us")),
         "env1_step_us": r3(dig(aux, "single_env", "env1_step_us")),
         "rlglue_step_us": r3(dig(aux, "single_env", "rlglue_env_step_us")),
-        "ref_cpu_step_us": r3(dig(aux, "single_env", "reference_cpu_us_per_step")),
+        "ref_cpu_step_us_build_container_const": r3(dig(aux, "single_env", "reference_cpu_us_per_step")),
         "estI_us": r3(dig(aux, "next_rows", "estimator_objective", "us_per_evaluation")),
         "v1_ms": r3(dig(aux, "next_rows", "ars_v1_iteration", "ms_per_iteration")),
         "topb_ms": r3(dig(aux, "next_rows", "ars_top_b_64_iteration", "ms_per_iteration")),
