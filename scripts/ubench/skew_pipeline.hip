@@ -461,6 +461,107 @@ __device__ __forceinline__ bool stream_reads<14>(uint32_t aseq, uint32_t adata, 
     return cnt < SPIN_CAP;
 }
 
+
+// the cautious reader: poll the sequence number ALONE (a miss costs one 4-byte LDS read, not the drain of all data
+// reads), then issue the data reads -- they cannot be stale -- and consume them as they arrive
+template <int NH>
+__device__ __forceinline__ bool two_phase_reads(uint32_t aseq, uint32_t adata, uint32_t expect, v2d (&p)[NH],
+                                                unsigned long long &spins);
+
+template <>
+__device__ __forceinline__ bool two_phase_reads<4>(uint32_t aseq, uint32_t adata, uint32_t expect, v2d (&p)[4],
+                                                     unsigned long long &spins)
+{
+    uint32_t s, cnt;
+    asm volatile("s_mov_b32 %[cnt], 0\n"
+                 ".Lsk2_retry_%=:\n\t"
+                 "ds_read_b32 %[s], %[as]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_cmp_ne_u32_e32 vcc, %[ex], %[s]\n\t"
+                 "s_cbranch_vccz .Lsk2_ok_%=\n\t"
+                 "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                 "s_cmp_lt_u32 %[cnt], %[cap]\n\t"
+                 "s_cbranch_scc1 .Lsk2_retry_%=\n"
+                 ".Lsk2_ok_%=:\n\t"
+                 "ds_read2st64_b64 %2, %[ad] offset0:0 offset1:1\n\t"
+                 "ds_read2st64_b64 %3, %[ad] offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b64 %4, %[ad] offset0:4 offset1:5\n\t"
+                 "ds_read2st64_b64 %5, %[ad] offset0:6 offset1:7\n\t"
+                 "s_nop 0"
+                 : [s] "=&v"(s), [cnt] "=&s"(cnt), "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+                 : [as] "v"(aseq), [ad] "v"(adata), [ex] "s"(expect), [cap] "s"(SPIN_CAP)
+                 : "vcc", "scc", "memory");
+    spins += cnt;
+    return cnt < SPIN_CAP;
+}
+
+template <>
+__device__ __forceinline__ bool two_phase_reads<7>(uint32_t aseq, uint32_t adata, uint32_t expect, v2d (&p)[7],
+                                                     unsigned long long &spins)
+{
+    uint32_t s, cnt;
+    asm volatile("s_mov_b32 %[cnt], 0\n"
+                 ".Lsk2_retry_%=:\n\t"
+                 "ds_read_b32 %[s], %[as]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_cmp_ne_u32_e32 vcc, %[ex], %[s]\n\t"
+                 "s_cbranch_vccz .Lsk2_ok_%=\n\t"
+                 "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                 "s_cmp_lt_u32 %[cnt], %[cap]\n\t"
+                 "s_cbranch_scc1 .Lsk2_retry_%=\n"
+                 ".Lsk2_ok_%=:\n\t"
+                 "ds_read2st64_b64 %2, %[ad] offset0:0 offset1:1\n\t"
+                 "ds_read2st64_b64 %3, %[ad] offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b64 %4, %[ad] offset0:4 offset1:5\n\t"
+                 "ds_read2st64_b64 %5, %[ad] offset0:6 offset1:7\n\t"
+                 "ds_read2st64_b64 %6, %[ad] offset0:8 offset1:9\n\t"
+                 "ds_read2st64_b64 %7, %[ad] offset0:10 offset1:11\n\t"
+                 "ds_read2st64_b64 %8, %[ad] offset0:12 offset1:13\n\t"
+                 "s_nop 0"
+                 : [s] "=&v"(s), [cnt] "=&s"(cnt), "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6])
+                 : [as] "v"(aseq), [ad] "v"(adata), [ex] "s"(expect), [cap] "s"(SPIN_CAP)
+                 : "vcc", "scc", "memory");
+    spins += cnt;
+    return cnt < SPIN_CAP;
+}
+
+template <>
+__device__ __forceinline__ bool two_phase_reads<14>(uint32_t aseq, uint32_t adata, uint32_t expect, v2d (&p)[14],
+                                                     unsigned long long &spins)
+{
+    uint32_t s, cnt;
+    asm volatile("s_mov_b32 %[cnt], 0\n"
+                 ".Lsk2_retry_%=:\n\t"
+                 "ds_read_b32 %[s], %[as]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_cmp_ne_u32_e32 vcc, %[ex], %[s]\n\t"
+                 "s_cbranch_vccz .Lsk2_ok_%=\n\t"
+                 "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                 "s_cmp_lt_u32 %[cnt], %[cap]\n\t"
+                 "s_cbranch_scc1 .Lsk2_retry_%=\n"
+                 ".Lsk2_ok_%=:\n\t"
+                 "ds_read2st64_b64 %2, %[ad] offset0:0 offset1:1\n\t"
+                 "ds_read2st64_b64 %3, %[ad] offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b64 %4, %[ad] offset0:4 offset1:5\n\t"
+                 "ds_read2st64_b64 %5, %[ad] offset0:6 offset1:7\n\t"
+                 "ds_read2st64_b64 %6, %[ad] offset0:8 offset1:9\n\t"
+                 "ds_read2st64_b64 %7, %[ad] offset0:10 offset1:11\n\t"
+                 "ds_read2st64_b64 %8, %[ad] offset0:12 offset1:13\n\t"
+                 "ds_read2st64_b64 %9, %[ad] offset0:14 offset1:15\n\t"
+                 "ds_read2st64_b64 %10, %[ad] offset0:16 offset1:17\n\t"
+                 "ds_read2st64_b64 %11, %[ad] offset0:18 offset1:19\n\t"
+                 "ds_read2st64_b64 %12, %[ad] offset0:20 offset1:21\n\t"
+                 "ds_read2st64_b64 %13, %[ad] offset0:22 offset1:23\n\t"
+                 "ds_read2st64_b64 %14, %[ad] offset0:24 offset1:25\n\t"
+                 "ds_read2st64_b64 %15, %[ad] offset0:26 offset1:27\n\t"
+                 "s_nop 0"
+                 : [s] "=&v"(s), [cnt] "=&s"(cnt), "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&v"(p[8]), "=&v"(p[9]), "=&v"(p[10]), "=&v"(p[11]), "=&v"(p[12]), "=&v"(p[13])
+                 : [as] "v"(aseq), [ad] "v"(adata), [ex] "s"(expect), [cap] "s"(SPIN_CAP)
+                 : "vcc", "scc", "memory");
+    spins += cnt;
+    return cnt < SPIN_CAP;
+}
+
 // spin on (sequence number, one double)
 __device__ __forceinline__ bool poll1(uint32_t aseq, uint32_t adata, uint32_t expect, double &v,
                                       unsigned long long &spins)
@@ -509,7 +610,7 @@ __device__ __forceinline__ void produce(uint32_t adata, double (&b)[8], double m
 
 // recurrence (one-wave form: skew1s):  G(t): b[0] += thd_t; for i < NH: WG/NH FMAs, geo_{t+1}[2i, 2i+1] = b[2i&7], b[(2i+1)&7]
 //                                      D(t): for i < NH: a[..] += geo_t[2i, 2i+1], WD/NH FMAs;  thd_{t+1} = a[0]
-template <int WG, int WD, int NH>
+template <int WG, int WD, int NH, bool TWO_PHASE = false>
 __global__ void __launch_bounds__(128) skew2s(Result *res, double *out, double seed, int iters)
 {
     __shared__ double geo[2][2 * NH][64];
@@ -552,7 +653,8 @@ __global__ void __launch_bounds__(128) skew2s(Result *res, double *out, double s
 #pragma nounroll
         for (int t = 0; t < iters && ok; ++t) {
             v2d p[NH];
-            ok = stream_reads<NH>(a_gs[t & 1], a_geo[t & 1], (uint32_t)t + 1u, p, spins);
+            ok = TWO_PHASE ? two_phase_reads<NH>(a_gs[t & 1], a_geo[t & 1], (uint32_t)t + 1u, p, spins)
+                           : stream_reads<NH>(a_gs[t & 1], a_geo[t & 1], (uint32_t)t + 1u, p, spins);
             consume<0, NH, WD>(p, a, m, c);
             lds_w1(a_th[(t + 1) & 1], a[0]);
             lds_wseq(a_ts[(t + 1) & 1], (uint32_t)t + 2u);
@@ -686,6 +788,12 @@ void run_skews(int blocks)
     run_pair("streamed", WG, WD, 2 * NH, skew1s<WG, WD, NH>, skew2s<WG, WD, NH>, blocks);
 }
 
+template <int WG, int WD, int NH>
+void run_skewt(int blocks)
+{
+    run_pair("2-phase ", WG, WD, 2 * NH, skew1s<WG, WD, NH>, skew2s<WG, WD, NH, true>, blocks);
+}
+
 template <int NX>
 void run_pingpong()
 {
@@ -756,5 +864,17 @@ int main()
     run_skews<126, 126, 14>(512);
     run_skews<126, 126, 14>(1024);
     run_skews<196, 196, 14>(1);    // n = 8-like
+    // ---- two-phase reader (sequence number polled alone)
+    run_skewt<0, 0, 4>(1);
+    run_skewt<0, 0, 7>(1);
+    run_skewt<0, 0, 14>(1);
+    run_skewt<56, 56, 4>(1);
+    run_skewt<56, 56, 7>(1);
+    run_skewt<42, 70, 7>(1);
+    run_skewt<112, 112, 7>(1);
+    run_skewt<126, 126, 14>(1);
+    run_skewt<98, 154, 14>(1);
+    run_skewt<126, 126, 14>(128);
+    run_skewt<196, 196, 14>(1);
     return 0;
 }
