@@ -546,6 +546,48 @@ def aux_next_rows(sw, torch, device, n=3, H=1000, directions=512):
     return out
 
 
+def aux_safe_gate(sw, torch, device, n=3, n_roll=1024, H=1000):
+    """SURVEY 8(f-1), third consumer: the safe-exploration gate (safe_ars/ars.py:111-153) at the size of a BASELINE
+    iteration -- 1024 rollouts x H = 1000, every real step preceded by a one-step simulator look-ahead and the cost
+    max_i |thetadot_i| (safe_ars/experiment.py:45), thresholds out of reach so that no lane ever stops (the most work
+    the gate can ask for: two physics steps per env-step).  Fused: ONE launch (sw_safe_rollouts_f64); lock step: the
+    same gate composed from two step-kernel launches + the mask per step (any Python cost callable), 40 steps timed."""
+    import numpy as np
+    rs = np.random.RandomState(3)
+    d, m = 2 * n + 2, n - 1
+    pol = torch.as_tensor(0.01 * (2 * rs.rand(n_roll, m, d) - 1), device=device)
+    p_real, p_sim = sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3), sw.SwParams.make(n)
+    traj = torch.empty((H, d, n_roll), dtype=torch.float64, device=device)
+    first = torch.empty(n_roll, dtype=torch.int32, device=device)
+
+    def go():
+        sw.kernels.safe_rollouts(p_real, p_sim, H, pol, sw._lib.COST_MAX_ABS_THETADOT, 0, 1e9, 1e9, traj=traj,
+                                 first_refused=first)
+    for _ in range(3):
+        go()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+    for a, b in ev:
+        a.record()
+        go()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)[4]
+    assert int((first != H).sum().item()) == 0
+    out = {"rollouts": n_roll, "horizon": H, "fused_ms_per_launch": ms, "env_steps_per_s": n_roll * H / (ms * 1e-3),
+           "physics_steps_per_s": 2 * n_roll * H / (ms * 1e-3),
+           "kernel": f"safe_rollout_kernel<{n}> (one rollout per lane, trajectory captured)"}
+    real = sw.SwimmerEnv(n=n, l_i=0.8, m_i=1.2, k=10.2, device=device)
+    agent = sw.safe_ars.Safe_ARS(sw.safe_ars.MaxAbsThetaDot(), 1e9, 1e9, sw.SwimmerEnv(n=n, device=device))
+    P = pol.cpu().numpy()
+    agent.rollouts(real, P, 8, fused=False)
+    t0 = time.perf_counter()
+    agent.rollouts(real, P, 40, fused=False)
+    out["lock_step_us_per_step"] = (time.perf_counter() - t0) / 40 * 1e6
+    out["lock_step_note"] = "per step of the whole 1024-rollout batch: two step-kernel launches + the cost and the mask in torch"
+    return out
+
+
 def aux_rollout_saturated(sw, torch, device, n=3, n_roll=262144, H=1000, reps=15):
     """Where the ROLLOUT path is HBM-bound: the lane-per-rollout kernel on a batch that fills the
     chip (262 144 rollouts x H = 1000) with every post-step state captured, 16.8 GB of stores."""
@@ -815,6 +857,8 @@ def summary(line, aux):
         "rlglue_step_us": r3(dig(aux, "single_env", "rlglue_env_step_us")),
         "ref_cpu_step_us_build_container_const": r3(dig(aux, "single_env", "reference_cpu_us_per_step")),
         "estI_us": r3(dig(aux, "next_rows", "estimator_objective", "us_per_evaluation")),
+        "gate_ms": r3(dig(aux, "next_rows", "safe_ars_gate", "fused_ms_per_launch")),
+        "gate_sps": r3(dig(aux, "next_rows", "safe_ars_gate", "env_steps_per_s")),
         "v1_ms": r3(dig(aux, "next_rows", "ars_v1_iteration", "ms_per_iteration")),
         "topb_ms": r3(dig(aux, "next_rows", "ars_top_b_64_iteration", "ms_per_iteration")),
         "cpu_sps": r3(dig(line, "cpu_baseline", "value")), "cpu_cores": dig(line, "cpu_baseline", "cores"),
@@ -1005,6 +1049,8 @@ def run_rank(args):
                       "n6": (aux.get("shard_n6_256_directions") or {}).get("ms_per_iteration")}
             aux["host_cost_at_8_ranks"] = guarded(aux_host_cost, sw, torch, device, gpu_ms)
             aux["next_rows"] = guarded(aux_next_rows, sw, torch, device)
+            if isinstance(aux["next_rows"], dict):
+                aux["next_rows"]["safe_ars_gate"] = guarded(aux_safe_gate, sw, torch, device)
             aux["rollout_saturated"] = guarded(aux_rollout_saturated, sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)

@@ -126,6 +126,27 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
                    double *returns, double *traj, double *final_state, double *moments,
                    int32_t *status, void *stream);
 
+/* Safe exploration, safe_ars/ars.py Safe_ARS.rollout (:124-153): n_roll rollouts of H steps from the reset state,
+ * every real step gated by a one-step look-ahead in a simulator -- isSafe (:111-122) = one step of the swimmer with
+ * the parameters `sim` from the real state under the proposed action policy @ obs (:139), and
+ * cost(simulated observation) <= sim_thresh.  A refused step leaves the state where it is (:150-151; the rollout
+ * then stays refused: it proposes the same action again).  `real` and `sim` must have the same number of segments;
+ * the model flag of `real` / `sim` is ignored (Gym model).  The whole loop is ONE launch, one rollout per lane.
+ *   policies      : [n_roll][m][d]
+ *   cost_kind     : SW_COST_ABS_OBS            cost = |obs[cost_index]|, obs = [Gdx, Gdy, th_1, thd_1, ...]
+ *                   SW_COST_MAX_ABS_THETADOT   cost = max_i |thetadot_i|  (safe_ars/experiment.py:45; cost_index unused)
+ *   returns       : [n_roll] sum of the rewards of the steps taken
+ *   traj          : NULL or [H][d][n_roll]: the state after step t, the unchanged state where step t was refused
+ *   first_refused : NULL or [n_roll]: the first refused step (H: none)
+ *   violations    : NULL or [n_roll]: real steps whose cost exceeded real_thresh (the reference prints each, :143-144)
+ *   status        : NULL or [n_roll] */
+#define SW_COST_ABS_OBS 0
+#define SW_COST_MAX_ABS_THETADOT 1
+int sw_safe_rollouts_f64(const sw_params *real, const sw_params *sim, int64_t n_roll, int32_t H,
+                         const double *policies, int32_t cost_kind, int32_t cost_index, double sim_thresh,
+                         double real_thresh, double *returns, double *traj, int32_t *first_refused,
+                         int32_t *violations, int32_t *status, void *stream);
+
 /* Number of partial-moment rows sw_rollout_f64 / sw_ars_rollouts_f64 write for n_roll
  * rollouts (= ceil(n_roll / 16), whichever kernel runs). */
 int64_t sw_moments_blocks(int64_t n_roll);

@@ -23,6 +23,8 @@ STATUS_RANGE = 4
 FLAG_ROLLOUT_LANE = 1   # sw_params.flags: force the lane-per-rollout kernel
 FLAG_ROLLOUT_QUAD = 2   # force the segment-per-lane kernels (quad: n = 3, row: n = 4..8)
 FLAG_MODEL_TWIN = 4     # integrate the native RL-Glue model (SwimmerEnvironment.cpp)
+COST_ABS_OBS = 0            # sw_safe_rollouts_f64: cost = |obs[index]|
+COST_MAX_ABS_THETADOT = 1   # cost = max_i |thetadot_i|
 
 
 class SwParams(ctypes.Structure):
@@ -71,6 +73,9 @@ _PROTOTYPES = {
     "sw_accel_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5),
     "sw_rollout_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
                        + [ctypes.c_void_p] * 10),
+    "sw_safe_rollouts_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                            ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
+                                            ctypes.c_double] + [ctypes.c_void_p] * 6),
     "sw_ars_rollouts_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_double] + [ctypes.c_void_p] * 7),

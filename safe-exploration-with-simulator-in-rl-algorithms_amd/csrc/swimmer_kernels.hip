@@ -505,6 +505,125 @@ rollout_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_roll, int32_t H, const 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Safe exploration (safe_ars/ars.py:101-153): every real step of a rollout is gated by a ONE-STEP look-ahead in a
+// simulator -- `isSafe` = sim_env.set_state(obs) + sim_env.step(action) + cost(sim obs) <= sim_thresh (:111-122,
+// called at :141).  One rollout per lane, the whole H-step loop in one launch: per step the action (policy @ obs,
+// :139), one Euler step with the SIMULATOR's constants on a copy of the state, the cost of where that lands, and --
+// if the gate is open -- the real step.  A refused step leaves the real env where it is (:150-151), so the same
+// action is proposed and refused for the rest of the horizon: the lane stops stepping and only repeats its state
+// into the trajectory.  Costs (include/swimmer_hip.h SW_COST_*): |obs[j]|, or max_i |thetadot_i| (the reference's
+// own experiment, safe_ars/experiment.py:45).
+template <int N>
+__device__ __forceinline__ double safe_cost(int32_t kind, int32_t index, double gdx, double gdy,
+                                            const double (&th)[N], const double (&thd)[N])
+{
+    if (kind == SW_COST_MAX_ABS_THETADOT) {
+        double c = fabs(thd[0]);
+#pragma unroll
+        for (int i = 1; i < N; ++i) c = fmax(c, fabs(thd[i]));   // np.max: NaN handled by the caller's <= test
+        bool nan = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) nan = nan || (thd[i] != thd[i]);
+        return nan ? __builtin_nan("") : c;                      // np.max propagates NaN, fmax would drop it
+    }
+    double v = (index == 0) ? gdx : gdy;                         // |obs[index]|, obs = [Gdx, Gdy, th_1, thd_1, ...]
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        v = (index == 2 + 2 * i) ? th[i] : v;
+        v = (index == 3 + 2 * i) ? thd[i] : v;
+    }
+    return fabs(v);
+}
+
+template <int N>
+__global__ void __launch_bounds__(kRollBlock)
+safe_rollout_kernel(sw::Consts Creal, sw::Consts Csim, int64_t n_roll, int32_t H,
+                    const double *__restrict__ policies, int32_t cost_kind, int32_t cost_index,
+                    double sim_thresh, double real_thresh, double *__restrict__ returns,
+                    double *__restrict__ traj, int32_t *__restrict__ first_refused,
+                    int32_t *__restrict__ violations, int32_t *__restrict__ status)
+{
+    constexpr int D = 2 * N + 2, M = N - 1;
+    const int64_t r = (int64_t)blockIdx.x * kRollBlock + threadIdx.x;
+    if (r >= n_roll) return;
+    double W[M][D];
+    const double *pl = policies + r * (M * D);
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) W[i][j] = pl[i * D + j];
+    double gdx = 0.0, gdy = 0.0, th[N], thd[N];      // real_env.reset() (:133)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        th[i] = kHalfPi;
+        thd[i] = 0.0;
+    }
+    auto record = [&](int32_t t) {
+        double *tp = traj + (int64_t)t * D * n_roll + r;
+        tp[0] = gdx;
+        tp[n_roll] = gdy;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            tp[(int64_t)(2 + 2 * i) * n_roll] = th[i];
+            tp[(int64_t)(3 + 2 * i) * n_roll] = thd[i];
+        }
+    };
+    double total = 0.0, thmax = 0.0;
+    bool ok = true;
+    int32_t refused_at = H, over = 0;
+    for (int32_t t = 0; t < H; ++t) {
+        thmax = sw::track_angle_range<N>(thmax, th);
+        double sm[D];
+        sm[0] = gdx;
+        sm[1] = gdy;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            sm[2 + 2 * i] = th[i];
+            sm[3 + 2 * i] = thd[i];
+        }
+        double u[M];                                  // ac = policy @ obs (:139)
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double a0 = W[i][0] * sm[0], a1 = W[i][1] * sm[1];
+#pragma unroll
+            for (int j = 2; j < D; j += 2) {
+                a0 = __builtin_fma(W[i][j], sm[j], a0);
+                a1 = __builtin_fma(W[i][j + 1], sm[j + 1], a1);
+            }
+            u[i] = a0 + a1;
+        }
+        // the simulator's look-ahead from the real state (:120-121)
+        double sgx = gdx, sgy = gdy, sth[N], sthd[N], srew;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            sth[i] = th[i];
+            sthd[i] = thd[i];
+        }
+        (void)sw::euler_step<N>(Csim, sgx, sgy, sth, sthd, u, srew);
+        if (!(safe_cost<N>(cost_kind, cost_index, sgx, sgy, sth, sthd) <= sim_thresh)) {   // :122, NaN refuses
+            refused_at = t;
+            break;
+        }
+        double rew;
+        ok = sw::euler_step<N>(Creal, gdx, gdy, th, thd, u, rew) && ok;                     // :142
+        total += rew;
+        over += (safe_cost<N>(cost_kind, cost_index, gdx, gdy, th, thd) > real_thresh) ? 1 : 0;   // :143-144
+        if (traj) record(t);
+    }
+    if (traj)
+        for (int32_t t = refused_at; t < H; ++t) record(t);      // :151: the unchanged state, step after step
+    bool fin = isfinite(gdx) && isfinite(gdy);
+#pragma unroll
+    for (int i = 0; i < N; ++i) fin = fin && isfinite(th[i]) && isfinite(thd[i]);
+    const bool in_range = thmax < sw::kAngleLimit;
+    returns[r] = in_range ? total : __builtin_nan("");
+    if (first_refused) first_refused[r] = refused_at;
+    if (violations) violations[r] = over;
+    if (status)
+        status[r] = (ok ? 0 : SW_STATUS_SINGULAR) | (fin ? 0 : SW_STATUS_NONFINITE) | (in_range ? 0 : SW_STATUS_RANGE);
+}
+
 constexpr int kMomBlock = 256;
 constexpr int kMomTChunk = 32;  // steps per 256-thread tile (8 measured slower: less work per workgroup)
 constexpr uint32_t kCovMaxTiles = 4096;   // tiles per pass: bounds the fixed-order merge
@@ -2186,6 +2305,31 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
                                                inv_std, state0, returns, traj, final_state, moments,
                                                status));
     }
+    return launch_status();
+}
+
+int sw_safe_rollouts_f64(const sw_params *real, const sw_params *sim, int64_t n_roll, int32_t H,
+                         const double *policies, int32_t cost_kind, int32_t cost_index, double sim_thresh,
+                         double real_thresh, double *returns, double *traj, int32_t *first_refused,
+                         int32_t *violations, int32_t *status, void *stream)
+{
+    int rc = check_params(real);
+    if (rc) return rc;
+    rc = validate_params(sim);
+    if (rc) return rc;
+    if (real->n != sim->n) return SW_ERR_SEGMENTS;
+    if (n_roll < 0 || H < 0) return SW_ERR_SIZE;
+    if (cost_kind != SW_COST_ABS_OBS && cost_kind != SW_COST_MAX_ABS_THETADOT) return SW_ERR_SIZE;
+    if (cost_kind == SW_COST_ABS_OBS && (cost_index < 0 || cost_index >= 2 * real->n + 2)) return SW_ERR_SIZE;
+    if (!(sim_thresh == sim_thresh) || !(real_thresh == real_thresh)) return SW_ERR_PARAM;
+    if (n_roll == 0) return SW_OK;
+    if (!policies || !returns) return SW_ERR_NULL;
+    const sw::Consts Cr = make_consts(real), Cs = make_consts(sim);
+    const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
+    SW_DISPATCH_N(real->n, hipLaunchKernelGGL((safe_rollout_kernel<NN>), dim3(grid), dim3(kRollBlock), 0,
+                                              (hipStream_t)stream, Cr, Cs, n_roll, H, policies, cost_kind,
+                                              cost_index, sim_thresh, real_thresh, returns, traj, first_refused,
+                                              violations, status));
     return launch_status();
 }
 

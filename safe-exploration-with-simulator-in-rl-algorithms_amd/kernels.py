@@ -215,6 +215,29 @@ def rollout(p: SwParams, H: int, policies, mean=None, inv_std=None, state0=None,
     return returns
 
 
+def safe_rollouts(p_real: SwParams, p_sim: SwParams, H: int, policies, cost_kind: int, cost_index: int,
+                  sim_thresh: float, real_thresh: float, traj=None, first_refused=None, violations=None,
+                  status=None, returns=None):
+    """safe_ars/ars.py Safe_ARS.rollout for a whole batch in ONE launch (sw_safe_rollouts_f64): n_roll rollouts of H
+    steps from the reset state, every real step gated by the one-step simulator look-ahead (`isSafe`, :111-122).
+    policies [n_roll, m, d]; optional outputs: traj [H, d, n_roll], first_refused / violations / status [n_roll] int32."""
+    require_gpu()
+    n_roll = policies.shape[0]
+    _want(policies, "policies", (n_roll, p_real.m, p_real.d))
+    dev = policies.device
+    if traj is not None:
+        _want(traj, "traj", (H, p_real.d, n_roll))
+    for name, t in (("first_refused", first_refused), ("violations", violations), ("status", status)):
+        if t is not None and (t.dtype != torch.int32 or tuple(t.shape) != (n_roll,)):
+            raise _lib.SwimmerHipError(f"{name}: expected int32 tensor of shape ({n_roll},)")
+    returns = _f64((n_roll,), dev) if returns is None else _want(returns, "returns", (n_roll,))
+    check(load().sw_safe_rollouts_f64(ctypes.byref(p_real), ctypes.byref(p_sim), n_roll, H, ptr(policies),
+                                      int(cost_kind), int(cost_index), float(sim_thresh), float(real_thresh),
+                                      ptr(returns), ptr(traj), ptr(first_refused), ptr(violations), ptr(status),
+                                      stream_ptr()), "sw_safe_rollouts_f64")
+    return returns
+
+
 def ars_rollouts(p: SwParams, H: int, policy, deltas, nu: float, dir_begin: int, n_dir: int,
                  mean=None, inv_std=None, returns=None, traj=None, moments=None, status=None):
     """The 2*n_dir exploration rollouts P +- nu*delta_i, i in [dir_begin, dir_begin+n_dir)."""

@@ -13,13 +13,46 @@ the batched form the other methods are built on.  `real_env` / `sim_env` are `Sw
 physical parameters are used: every rollout starts from `reset()`, :125).  `cost` is the reference's callable on
 an observation; it is evaluated ONCE per step on the whole batch as a [d, B] tensor -- `abs(obs[3])` works
 unchanged -- and falls back to one call per swimmer for callables that cannot take tensors.
+A cost given as one of the NATIVE cost objects below (`AbsObs(j)`: |obs[j]|; `MaxAbsThetaDot()`: max_i |thetadot_i|,
+the reference experiment's own cost, safe_ars/experiment.py:45) runs the whole gated H-step loop of all rollouts in
+ONE kernel launch (`sw_safe_rollouts_f64`: action, simulator look-ahead, cost, gate, real step -- all in registers);
+any other callable takes the lock-step path.  The native cost objects are ordinary callables too (lists, arrays and
+[d, B] tensors), so they can be handed to the reference's own classes unchanged.
 No CPU fallback for the physics: every step goes through the C ABI.
 """
 import numpy as np
 import torch
 
 from .. import kernels
-from .._lib import SwParams, numpy_global_uniform_pm1, require_gpu
+from .._lib import (COST_ABS_OBS, COST_MAX_ABS_THETADOT, SwParams, numpy_global_uniform_pm1, require_gpu)
+
+
+class NativeCost(object):
+    """A state cost the fused kernel evaluates itself (kind / index of include/swimmer_hip.h SW_COST_*)."""
+    kind, index = None, 0
+
+
+class AbsObs(NativeCost):
+    """cost(obs) = |obs[index]|, obs = [Gdot_x, Gdot_y, theta_1, thetadot_1, ...]."""
+    kind = COST_ABS_OBS
+
+    def __init__(self, index):
+        self.index = int(index)
+
+    def __call__(self, obs):
+        return abs(obs[self.index])
+
+
+class MaxAbsThetaDot(NativeCost):
+    """cost(obs) = max_i |thetadot_i| -- "maximum speed angle", safe_ars/experiment.py:43-45."""
+    kind = COST_MAX_ABS_THETADOT
+
+    def __call__(self, obs):
+        n = (len(obs) - 2) // 2
+        vals = [abs(obs[3 + 2 * i]) for i in range(n)]
+        if isinstance(vals[0], torch.Tensor):
+            return torch.stack(vals).max(dim=0).values
+        return np.max(vals)
 
 
 def _params(env):
@@ -121,9 +154,34 @@ class Safe_ARS(Basic_ARS):
         self.sim_env = sim_env
         self.real_violations = 0      # real steps whose cost exceeded real_thresh (the reference prints each, :143-144)
 
+    def rollouts(self, real_env, policies, H, fused=None):
+        """B gated rollouts.  fused=None: ONE launch of the fused kernel when `cost` is a NativeCost, the lock-step
+        path otherwise; fused=False forces the lock-step path (same results: tests/test_hip_parity.py)."""
+        native = isinstance(self.cost, NativeCost)
+        if fused is None:
+            fused = native
+        if not fused:
+            return super().rollouts(real_env, policies, H)
+        if not native:
+            raise TypeError("the fused gate needs a NativeCost (AbsObs / MaxAbsThetaDot); other callables take the "
+                            "lock-step path (fused=False)")
+        require_gpu()
+        dev = getattr(real_env, "device", torch.device("cuda:0"))
+        p_real, p_sim = _params(real_env), _params(self.sim_env)
+        P = torch.as_tensor(np.ascontiguousarray(policies, dtype=np.float64), device=dev)
+        B, d = P.shape[0], p_real.d
+        traj = torch.empty((H, d, B), dtype=torch.float64, device=dev)
+        over = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.first_refused = torch.empty(B, dtype=torch.int32, device=dev)
+        R = kernels.safe_rollouts(p_real, p_sim, H, P, self.cost.kind, self.cost.index, self.sim_thresh,
+                                  self.real_thresh, traj=traj, first_refused=self.first_refused, violations=over)
+        self.real_violations += int(over.sum().item())
+        return R.cpu().numpy(), traj.permute(2, 0, 1).cpu().numpy()
+
     def _prepare(self, B, d, dev):
         self._p_sim = _params(self.sim_env)
         self._sim_next = torch.empty((d, B), dtype=torch.float64, device=dev)
+        self._sim_rew = torch.empty(B, dtype=torch.float64, device=dev)
 
     def _cost_batch(self, obs):
         """cost over a [d, B] batch -> [B] tensor (one tensor call; per-swimmer calls if the callable refuses)."""
@@ -145,7 +203,7 @@ class Safe_ARS(Basic_ARS):
         return cost(obs) <= thresh
 
     def _gate(self, state, action):
-        kernels.step(self._p_sim, state, action, out=self._sim_next)       # set_state(obs) + step(ac) for all B
+        kernels.step(self._p_sim, state, action, out=self._sim_next, reward=self._sim_rew)   # set_state(obs) + step(ac), all B
         return self._cost_batch(self._sim_next) <= self.sim_thresh
 
     def _after_real_step(self, nxt, safe):

@@ -565,6 +565,31 @@ def gen_safe_ars():
     out["rollout_first_refused"] = first
     print("safe_ars: first refused step per policy", first.tolist(), "returns", R)
 
+    # (a') the same policies under the reference experiment's own cost, "maximum speed angle"
+    #      (safe_ars/experiment.py:43-45: np.max of |thetadot_i|), n = 3 and a 6-segment chain
+    def cost_max(x):
+        return np.max([abs(x[3 + 2 * i]) for i in range((len(x) - 2) // 2)])
+
+    for tag, nn, thr in (("max3", 3, (0.45, 0.5)), ("max6", 6, (0.8, 0.9))):
+        rs2 = np.random.RandomState(78 + nn)
+        pols2 = np.stack([sc * (2 * rs2.rand(nn - 1, 2 * nn + 2) - 1) for sc in (0.05, 0.4, 0.8, 1.2, 2.0, 3.0)])
+        agent = arsmod.Safe_ARS(cost_max, thr[1], thr[0], make_env(nn, "default"))
+        R2 = np.empty(len(pols2))
+        st2 = np.empty((len(pols2), H, 2 * nn + 2))
+        with contextlib.redirect_stdout(io.StringIO()):
+            for i, P in enumerate(pols2):
+                R2[i], st = agent.rollout(make_env(nn, "realworld"), P, H)
+                st2[i] = np.array(st)
+        same = np.all(st2[:, 1:] == st2[:, :-1], axis=2)
+        first2 = np.array([int(np.argmax(q)) + 1 if q.any() else H for q in same])
+        out[tag + "_cfg"] = np.array([nn, H], dtype=np.int64)
+        out[tag + "_thresholds"] = np.array(thr)
+        out[tag + "_policies"] = pols2
+        out[tag + "_returns"] = R2
+        out[tag + "_states"] = st2
+        out[tag + "_first_refused"] = first2
+        print("safe_ars", tag, "first refused step per policy", first2.tolist())
+
     N, b, Ht, alpha, nu, seed, iters = 6, 3, 60, 0.02, 0.9, 11, 3
     tp = np.empty((iters, n - 1, 2 * n + 2))
     curves = []

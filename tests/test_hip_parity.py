@@ -801,6 +801,63 @@ def test_safe_ars_gate_vs_reference(sw, golden):
     assert np.abs(states[-2 * N:] - g["train_last_states"]).max() <= 1e-9
 
 
+def test_fused_safe_rollouts_vs_reference(sw, golden):
+    """The gated rollout as ONE launch (sw_safe_rollouts_f64: action, simulator look-ahead, cost, gate and real step in
+    registers, one rollout per lane) for the native costs: |obs[3]| against the fixtures of the test above, and the
+    reference experiment's own cost max_i |thetadot_i| (safe_ars/experiment.py:45) at n = 3 and n = 6 -- against
+    the REFERENCE's Safe_ARS.rollout outputs, and bit for bit against the lock-step path on the gate's decisions."""
+    g = golden.safe_ars
+    n, H = (int(v) for v in g["cfg"])
+    sim_thresh, real_thresh = (float(v) for v in g["thresholds"])
+    rp, sp = [float(v) for v in g["real_phys"]], [float(v) for v in g["sim_phys"]]
+
+    def envs(nn):
+        return (sw.SwimmerEnv(n=nn, l_i=rp[0], m_i=rp[1], k=rp[2], h=rp[3]),
+                sw.SwimmerEnv(n=nn, l_i=sp[0], m_i=sp[1], k=sp[2], h=sp[3]))
+    real, sim = envs(n)
+    agent = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), real_thresh, sim_thresh, sim)
+    R, st = agent.rollouts(real, g["rollout_policies"], H)                        # fused: one launch
+    assert np.abs(st - g["rollout_states"]).max() <= 1e-10 and np.abs(R - g["rollout_returns"]).max() <= 1e-12
+    assert agent.first_refused.cpu().numpy().tolist() == g["rollout_first_refused"].tolist()
+    R2, st2 = agent.rollouts(real, g["rollout_policies"], H, fused=False)          # lock-step path, same cost object
+    assert np.abs(st2 - st).max() <= 1e-12 and np.abs(R2 - R).max() <= 1e-13
+    for tag in ("max3", "max6"):
+        nn, HH = (int(v) for v in g[tag + "_cfg"])
+        thr = [float(v) for v in g[tag + "_thresholds"]]
+        real, sim = envs(nn)
+        a = sw.safe_ars.Safe_ARS(sw.safe_ars.MaxAbsThetaDot(), thr[1], thr[0], sim)
+        R, st = a.rollouts(real, g[tag + "_policies"], HH)
+        assert np.abs(st - g[tag + "_states"]).max() <= 1e-10 and np.abs(R - g[tag + "_returns"]).max() <= 1e-12
+        assert a.first_refused.cpu().numpy().tolist() == g[tag + "_first_refused"].tolist()
+        Rl, stl = a.rollouts(real, g[tag + "_policies"], HH, fused=False)
+        assert np.abs(stl - st).max() <= 1e-12
+        # the reference's own lambda (np.max over a list: refuses tensors -> per-swimmer fallback) gives the same again
+        ref_cost = lambda x: np.max([abs(x[3 + 2 * i]) for i in range(nn)])        # noqa: E731
+        Rp, stp = sw.safe_ars.Safe_ARS(ref_cost, thr[1], thr[0], sim).rollouts(real, g[tag + "_policies"], HH)
+        assert np.array_equal(stp, stl) and np.array_equal(Rp, Rl)
+    # training through the fused path: the reference's three iterations
+    N, b, Ht, seed, iters = (int(v) for v in g["train_cfg"])
+    alpha, nu = (float(v) for v in g["train_hyper"])
+    real, sim = envs(n)
+    np.random.seed(seed)
+    a = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), real_thresh, sim_thresh, sim)
+    curve, states = a.train(iters, real, N, b, alpha, nu, Ht)
+    assert np.abs(a.policy - g["train_policies"][iters - 1]).max() <= 1e-9
+    assert np.abs(curve - g["train_curve"]).max() <= 1e-12
+    assert np.abs(states[-2 * N:] - g["train_last_states"]).max() <= 1e-9
+    # argument checks of the C entry point
+    p3, p4 = sw.SwParams.make(3), sw.SwParams.make(4)
+    pol = torch.zeros((4, 2, 8), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.safe_rollouts(p3, p4, 10, pol, 0, 3, 1.0, 1.0)                  # different chains
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.safe_rollouts(p3, p3, 10, pol, 0, 8, 1.0, 1.0)                  # cost index outside the observation
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.safe_rollouts(p3, p3, 10, pol, 7, 0, 1.0, 1.0)                  # unknown cost
+    r0 = sw.kernels.safe_rollouts(p3, p3, 0, pol, 1, 0, 1.0, 1.0)                  # H = 0
+    assert torch.equal(r0, torch.zeros(4, dtype=torch.float64, device="cuda:0"))
+
+
 def test_basic_ars_mirror_vs_reference(sw, golden):
     """safe_ars.Basic_ARS (the ungated parent class): `train` against the reference's Basic_ARS.train goldens."""
     g = golden.next_rows

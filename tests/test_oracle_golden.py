@@ -224,6 +224,19 @@ def test_safe_ars_oracle_vs_reference(golden):
         firsts.append(int(np.argmax(same)) + 1 if same.any() else H)
     assert firsts == g["rollout_first_refused"].tolist()          # the gate closes at the reference's steps
     assert len(set(firsts)) >= 5 and H in firsts                  # the fixture exercises the gate
+    # the reference experiment's own cost, max_i |thetadot_i| (safe_ars/experiment.py:45), n = 3 and n = 6
+    cost_max = lambda x: np.max([abs(x[3 + 2 * i]) for i in range((len(x) - 2) // 2)])      # noqa: E731
+    for tag in ("max3", "max6"):
+        nn, HH = (int(v) for v in g[tag + "_cfg"])
+        thr = [float(v) for v in g[tag + "_thresholds"]]
+        pr = oracle.OracleParams.make(nn, *[float(v) for v in g["real_phys"]])
+        ps = oracle.OracleParams.make(nn, *[float(v) for v in g["sim_phys"]])
+        for P, R_ref, st_ref, f_ref in zip(g[tag + "_policies"], g[tag + "_returns"], g[tag + "_states"],
+                                           g[tag + "_first_refused"]):
+            R, st = sao.safe_rollout(pr, ps, cost_max, thr[0], P, HH)
+            assert np.abs(st - st_ref).max() <= 1e-12 and abs(R - R_ref) <= 1e-13
+            same = np.all(st[1:] == st[:-1], axis=1)
+            assert (int(np.argmax(same)) + 1 if same.any() else HH) == int(f_ref)
     N, b, Ht, seed, iters = (int(v) for v in g["train_cfg"])
     alpha, nu = (float(v) for v in g["train_hyper"])
     pols, curve = sao.safe_train(p_real, p_sim, cost, sim_thresh, iters, N, b, alpha, nu, Ht, seed)
