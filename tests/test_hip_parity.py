@@ -917,3 +917,47 @@ def test_violent_accelerations_inside_an_unchecked_trip(sw, n):
     assert acc0.max() > 3000.0                 # the in-trip gain really exceeds what `too_fast` allows for
     assert rel <= 1e-6
     assert abs_err[tame].max() <= 1e-5
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])
+def test_fused_safe_rollouts_vs_oracle_every_chain_length(sw, n):
+    """sw_safe_rollouts_f64 for every supported chain length against oracle/safe_ars_oracle.py (pinned to the
+    reference's Safe_ARS at n = 3 and 6): a ragged batch (not a multiple of the 64-lane workgroup), both native costs,
+    thresholds that refuse some rollouts at step 0, some midway, some never; first-refused step, per-rollout violation
+    counts, returns and every state of the trajectory."""
+    from oracle import safe_ars_oracle as sao
+    rs = np.random.RandomState(300 + n)
+    d, m, H, R = 2 * n + 2, n - 1, 50, 70
+    scales = np.concatenate([np.full(10, 0.0), rs.uniform(0.05, 3.0, R - 10)])
+    pol = scales[:, None, None] * (2 * rs.rand(R, m, d) - 1)
+    p_real, p_sim = oracle.OracleParams.make(n, 0.8, 1.2, 10.2, 1e-3), oracle.OracleParams.make(n, 1.0, 1.0, 10.0, 1e-3)
+    s_real, s_sim = sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3), sw.SwParams.make(n, 1.0, 1.0, 10.0, 1e-3)
+    costs = ((sw._lib.COST_ABS_OBS, 3, lambda ob: abs(ob[3])),
+             (sw._lib.COST_ABS_OBS, 2 * n, lambda ob: abs(ob[2 * n])),                 # |theta_n|: starts at pi/2
+             (sw._lib.COST_MAX_ABS_THETADOT, 0, lambda ob: np.max([abs(ob[3 + 2 * i]) for i in range(n)])))
+    for kind, index, cost in costs:
+        for sim_thresh, real_thresh in ((0.25, 0.2), (-1.0, 0.0), (1.6, 1.58)):
+            traj = torch.empty((H, d, R), dtype=torch.float64, device="cuda:0")
+            first = torch.empty(R, dtype=torch.int32, device="cuda:0")
+            viol = torch.empty(R, dtype=torch.int32, device="cuda:0")
+            status = torch.empty(R, dtype=torch.int32, device="cuda:0")
+            ret = sw.kernels.safe_rollouts(s_real, s_sim, H, torch.as_tensor(pol, device="cuda:0"), kind, index,
+                                           sim_thresh, real_thresh, traj=traj, first_refused=first, violations=viol,
+                                           status=status)
+            got = traj.permute(2, 0, 1).cpu().numpy()
+            assert int(status.abs().sum()) == 0
+            for r in range(0, R, 3):
+                Ro, sto = sao.safe_rollout(p_real, p_sim, cost, sim_thresh, pol[r], H)
+                assert np.abs(got[r] - sto).max() <= 1e-10 * max(1.0, np.abs(sto).max())
+                assert abs(float(ret[r]) - Ro) <= 1e-11 * max(1.0, abs(Ro))
+                same = np.all(sto[1:] == sto[:-1], axis=1)
+                reset = oracle.reset(p_real)
+                f_ref = 0 if np.array_equal(sto[0], reset) and same.all() else (int(np.argmax(same)) + 1 if same.any() else H)
+                # a zero policy never moves the swimmer: "refused at 0" and "never refused" look alike in the states;
+                # the kernel's own bookkeeping decides, the oracle's gate is re-evaluated for it
+                if scales[r] == 0.0:
+                    sim_obs, _ = oracle.step(p_sim, reset, np.zeros(m))
+                    f_ref = H if cost(sim_obs) <= sim_thresh else 0
+                assert int(first[r]) == f_ref, (n, kind, index, sim_thresh, r, int(first[r]), f_ref)
+                taken = sto[:f_ref]
+                assert int(viol[r]) == int(sum(cost(ob) > real_thresh for ob in taken))
