@@ -2,23 +2,24 @@
 
 The reference runs its 2N rollouts one after the other, and inside a `Safe_ARS` rollout every real step is
 gated by a ONE-STEP look-ahead in a simulator: `isSafe` = `sim_env.set_state(obs)` + `sim_env.step(action)` +
-`cost(sim obs) <= sim_thresh` (:111-122, called at :141).  That look-ahead is exactly the batched
-set_state + step surface of the step kernel (SURVEY 8f-1's third consumer), so here ALL rollouts advance in lock
-step: per step two launches of `sw_step_f64` over the whole batch (simulator parameters, real parameters, the same
-states and actions) and the gate as a mask -- a refused swimmer keeps its state (:150-151), which makes it propose
-the same action again, so it stays refused for the rest of the horizon, as in the reference.
+`cost(sim obs) <= sim_thresh` (:111-122, called at :141) -- exactly the batched set_state + step surface of the step
+kernel (SURVEY 8f-1's third consumer).  Here a batch of rollouts is
 
-Same class names, constructor arguments, method names and return types as the reference; `rollouts` (plural) is
-the batched form the other methods are built on.  `real_env` / `sim_env` are `SwimmerEnv` objects (only their
-physical parameters are used: every rollout starts from `reset()`, :125).  `cost` is the reference's callable on
-an observation; it is evaluated ONCE per step on the whole batch as a [d, B] tensor -- `abs(obs[3])` works
-unchanged -- and falls back to one call per swimmer for callables that cannot take tensors.
-A cost given as one of the NATIVE cost objects below (`AbsObs(j)`: |obs[j]|; `MaxAbsThetaDot()`: max_i |thetadot_i|,
-the reference experiment's own cost, safe_ars/experiment.py:45) runs the whole gated H-step loop of all rollouts in
-ONE kernel launch (`sw_safe_rollouts_f64`: action, simulator look-ahead, cost, gate, real step -- all in registers);
-any other callable takes the lock-step path.  The native cost objects are ordinary callables too (lists, arrays and
-[d, B] tensors), so they can be handed to the reference's own classes unchanged.
-No CPU fallback for the physics: every step goes through the C ABI.
+  * `Basic_ARS`: ONE launch of the rollout kernels (`sw_rollout_f64`; the action `policy @ obs` of :26 is ARS V1's);
+  * `Safe_ARS` with a NATIVE cost (`AbsObs(j)`: |obs[j]|; `MaxAbsThetaDot()`: max_i |thetadot_i|, the reference
+    experiment's own cost, safe_ars/experiment.py:45): ONE launch of the fused gate kernel (`sw_safe_rollouts_f64`:
+    action, simulator look-ahead, cost, gate, real step -- all in registers, one rollout per lane);
+  * `Safe_ARS` with any other cost callable: all rollouts in LOCK STEP, per step two launches of `sw_step_f64` over the
+    whole batch (simulator parameters, real parameters, the same states and actions), the cost evaluated once on the
+    batch as a [d, B] tensor -- `abs(obs[3])` works unchanged -- with a per-swimmer fallback for callables that cannot
+    take tensors, and the gate as a mask.
+
+A refused swimmer keeps its state (:150-151), which makes it propose the same action again, so it stays refused for
+the rest of the horizon, as in the reference.  Same class names, constructor arguments, method names and return types
+as the reference; `rollouts` (plural) is the batched form the other methods are built on.  `real_env` / `sim_env` are
+`SwimmerEnv` objects (only their physical parameters are used: every rollout starts from `reset()`, :125).  The native
+cost objects are ordinary callables too (lists, arrays, [d, B] tensors), so they can be handed to the reference's own
+classes unchanged.  No CPU fallback for the physics: every step goes through the C ABI.
 """
 import numpy as np
 import torch
@@ -66,8 +67,22 @@ class Basic_ARS(object):
         return None
 
     def rollouts(self, real_env, policies, H):
-        """B rollouts of H steps in lock step.  policies: [B, m, d].  Returns (returns [B], states [B, H, d]) as
-        NumPy arrays; states[b, t] is the observation after step t (the unchanged one where step t was refused)."""
+        """B rollouts of H steps.  policies: [B, m, d].  Returns (returns [B], states [B, H, d]) as NumPy arrays;
+        states[b, t] is the observation after step t.  ONE launch of the rollout kernels (`sw_rollout_f64`, the V1
+        action policy @ obs of :26): Basic_ARS.rollout is Environment.rollout without the whitening."""
+        require_gpu()
+        dev = getattr(real_env, "device", torch.device("cuda:0"))
+        p_real = _params(real_env)
+        P = torch.as_tensor(np.ascontiguousarray(policies, dtype=np.float64), device=dev)
+        B, m, d = P.shape
+        assert (m, d) == (p_real.m, p_real.d), f"policies must be [B, {p_real.m}, {p_real.d}]"
+        traj = torch.empty((H, d, B), dtype=torch.float64, device=dev)
+        R = kernels.rollout(p_real, H, P, traj=traj)
+        return R.cpu().numpy(), traj.permute(2, 0, 1).cpu().numpy()
+
+    def _lock_step_rollouts(self, real_env, policies, H):
+        """The generic form: all rollouts advance one step at a time, `_gate` decides per swimmer whether the real
+        step is taken (states[b, t] is the unchanged observation where step t was refused)."""
         require_gpu()
         dev = getattr(real_env, "device", torch.device("cuda:0"))
         p_real = _params(real_env)
@@ -161,7 +176,7 @@ class Safe_ARS(Basic_ARS):
         if fused is None:
             fused = native
         if not fused:
-            return super().rollouts(real_env, policies, H)
+            return self._lock_step_rollouts(real_env, policies, H)
         if not native:
             raise TypeError("the fused gate needs a NativeCost (AbsObs / MaxAbsThetaDot); other callables take the "
                             "lock-step path (fused=False)")
