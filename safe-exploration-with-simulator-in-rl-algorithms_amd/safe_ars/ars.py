@@ -121,19 +121,17 @@ class Basic_ARS(object):
         return float(R[0]), st[0].tolist()
 
     def sort_directions(self, deltas, rewards):
-        max_rewards = [max(rewards[2 * i], rewards[2 * i + 1]) for i in range(len(deltas))]
-        return np.argsort(max_rewards).tolist()[::-1]
+        """Directions by max(r+, r-), best first (:33-44): the same ascending argsort, reversed, as the reference."""
+        pairs = np.asarray(rewards, dtype=np.float64).reshape(-1, 2)[:len(deltas)]
+        return np.argsort(pairs.max(axis=1)).tolist()[::-1]
 
     def update_policy(self, deltas, returns, order, alpha):
-        used = []
-        for i in order:
-            used += [returns[2 * i], returns[2 * i + 1]]
-        sigma_r = np.std(used)
-        grad = np.zeros(self.policy.shape)
-        for i in order:
-            grad += (returns[2 * i] - returns[2 * i + 1]) * deltas[i]
-        grad /= (len(order) * sigma_r)
-        self.policy += alpha * grad
+        """:46-65 -- sigma_R (ddof 0) over the returns of the directions in `order`, step = sum (r+ - r-) delta
+        over them, divided by len(order) * sigma_R."""
+        idx = np.asarray(order, dtype=np.int64)
+        pairs = np.asarray(returns, dtype=np.float64).reshape(-1, 2)[idx]      # rows [r_i+, r_i-] in `order`
+        step = np.tensordot(pairs[:, 0] - pairs[:, 1], np.asarray(deltas, dtype=np.float64)[idx], axes=1)
+        self.policy += alpha * step / (len(idx) * np.std(pairs))
 
     def train(self, n_iter, real_env, N, b, alpha, nu, H):
         """safe_ars/ars.py:67-98 with the 2N rollouts of an iteration as ONE lock-step batch.  The noise comes
