@@ -21,6 +21,8 @@
  *   sw_traj_moments_f64  np.mean / np.cov over the saved states     ars/ars_agent.py:180-182
  *   sw_env1_step         the same step for ONE swimmer handed over in host memory (the Gym
  *                        surface and the RL-Glue env_step, SwimmerEnvironment.cpp:53-68)
+ *   sw_safe_rollouts_f64 Safe_ARS.isSafe + Safe_ARS.rollout (the one-step simulator look-ahead that gates
+ *                        every real step)                            safe_ars/ars.py:111-153
  *
  * Layouts (d = 2n+2 observation size, m = n-1 action size):
  *   state, SoA    [d][n_env]   field-major: row f holds field f of every env; fields are
