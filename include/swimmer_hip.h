@@ -21,6 +21,8 @@
  *   sw_traj_moments_f64  np.mean / np.cov over the saved states     ars/ars_agent.py:180-182
  *   sw_env1_step         the same step for ONE swimmer handed over in host memory (the Gym
  *                        surface and the RL-Glue env_step, SwimmerEnvironment.cpp:53-68)
+ *   sw_step_residual_f64 Estimator.I: every stored transition re-simulated and compared with its stored next
+ *                        state                                       ars/estimator.py:36-62
  *   sw_safe_rollouts_f64 Safe_ARS.isSafe + Safe_ARS.rollout (the one-step simulator look-ahead that gates
  *                        every real step)                            safe_ars/ars.py:111-153
  *
@@ -109,6 +111,15 @@ int sw_step_f64(const sw_params *p, int64_t n_env, const double *state_in,
                 int32_t *status, void *stream);
 
 /* Accelerations only: gdd [2][n_env], tdd [n][n_env]. */
+/* The estimator's objective in one pass (ars/estimator.py:36-62): for every stored transition (state, action,
+ * stored next state; SoA like sw_step_f64) the Euclidean distance || step(state, action) - next_ref ||_2, summed in a
+ * fixed order per workgroup: partial[b] = sum over transitions [b * B, (b + 1) * B), B = n_env / sw_step_residual_blocks
+ * rounded up to the workgroup size (256).  I(x) is the sum of `partial` (sw_step_residual_blocks(n_env) doubles).  Nothing
+ * else is written: the simulated next states never reach memory.  Gym model only (SW_FLAG_MODEL_TWIN: SW_ERR_PARAM). */
+int sw_step_residual_f64(const sw_params *p, int64_t n_env, const double *state, const double *action,
+                         const double *next_ref, double *partial, void *stream);
+int64_t sw_step_residual_blocks(int64_t n_env);
+
 int sw_accel_f64(const sw_params *p, int64_t n_env, const double *state,
                  const double *action, double *gdd, double *tdd, void *stream);
 

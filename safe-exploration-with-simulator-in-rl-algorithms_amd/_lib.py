@@ -70,6 +70,8 @@ _PROTOTYPES = {
     "sw_reset_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p]),
     "sw_step_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 6),
+    "sw_step_residual_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5),
+    "sw_step_residual_blocks": (ctypes.c_int64, [ctypes.c_int64]),
     "sw_accel_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5),
     "sw_rollout_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
                        + [ctypes.c_void_p] * 10),

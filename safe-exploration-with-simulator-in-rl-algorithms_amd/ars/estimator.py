@@ -4,8 +4,9 @@
 The reference evaluates its objective I(x) by looping over every stored transition:
 `set_state(s)`, `step(select_action(policy, s))`, compare with the stored next state
 (estimator.py:50-55) -- an embarrassingly parallel batch of single physics steps.  Here all
-transitions of all selected trajectories go through ONE launch of the step kernel
-(sw_step_f64); J(x) is one launch of the rollout kernel.  The CMA-ES search around them
+transitions of all selected trajectories go through ONE launch that steps every transition AND
+compares it with its stored next state (sw_step_residual_f64: the simulated states never reach
+memory); J(x) is one launch of the rollout kernel.  The CMA-ES search around them
 (estimator.py:89-110) is orchestration and needs the `cma` package, which is optional.
 """
 import dataclasses
@@ -34,6 +35,7 @@ class Estimator(object):
         self.iter = 0
         self.device = torch.device(device)
         self._cache = None
+        self._partial = None
 
     def convert_to_env_param(self, x):
         d = dataclasses.asdict(self.guess_param)
@@ -99,8 +101,13 @@ class Estimator(object):
     def I(self, x):
         """Sum over stored transitions of || sim_step(s_t, a_t) - s_{t+1} ||_2."""
         states, nexts, actions, _ = self._batch()
-        sim, _ = kernels.step(self._params(x), states, actions)
-        return float(torch.linalg.vector_norm(sim - nexts, ord=2, dim=0).sum().item())
+        # one pass: step + distance to the stored next state + per-workgroup sums (sw_step_residual_f64); the
+        # simulated states are never written, only T / 256 partial sums are
+        if self._partial is None or self._partial.shape[0] != kernels.step_residual_blocks(states.shape[1]):
+            self._partial = torch.empty(kernels.step_residual_blocks(states.shape[1]), dtype=torch.float64,
+                                        device=self.device)
+        kernels.step_residual(self._params(x), states, actions, nexts, partial=self._partial)
+        return float(self._partial.sum().item())
 
     def J(self, x):
         """Deprecated objective of the reference (estimator.py:64-87): whole-rollout distance."""

@@ -216,6 +216,62 @@ step_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_env, const double *__restr
                     (in_range ? 0 : SW_STATUS_RANGE);
 }
 
+// One physics step per stored transition, COMPARED with the stored next state instead of written out: the
+// estimator's objective I(x) (ars/estimator.py:36-62) is the sum over every stored transition of
+// || sim_step(s_t, a_t) - s_{t+1} ||_2.  Reads state + action + stored next state (16 d + 8 m bytes per transition),
+// writes ONE double per workgroup: the fixed-order sum of its transitions' distances (lanes by shuffle tree, the four
+// waves in order) -- deterministic, and the d doubles per transition the step kernel would store, the difference
+// kernel would read back and the norm kernel would reduce never exist.  Out-of-range angles give NaN (as in step_kernel).
+template <int N, bool NT>
+__global__ void __launch_bounds__(kStepBlock)
+step_residual_kernel(sw::Consts C, int64_t n_env, const double *__restrict__ sin_, const double *__restrict__ act,
+                     const double *__restrict__ next_ref, double *__restrict__ partial)
+{
+    constexpr int M = N - 1;
+    __shared__ double wsum[kStepBlock / kWave];
+    const int64_t e = (int64_t)blockIdx.x * kStepBlock + threadIdx.x;
+    double dist = 0.0;
+    if (e < n_env) {
+        double gdx = SW_LD(&sin_[e]), gdy = SW_LD(&sin_[n_env + e]);
+        double th[N], thd[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            th[i] = SW_LD(&sin_[(int64_t)(2 + 2 * i) * n_env + e]);
+            thd[i] = SW_LD(&sin_[(int64_t)(3 + 2 * i) * n_env + e]);
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) u[i] = SW_LD(&act[(int64_t)i * n_env + e]);
+        // the stored next state: its loads are in flight while the step is computed
+        double rx = SW_LD(&next_ref[e]), ry = SW_LD(&next_ref[n_env + e]), rth[N], rthd[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            rth[i] = SW_LD(&next_ref[(int64_t)(2 + 2 * i) * n_env + e]);
+            rthd[i] = SW_LD(&next_ref[(int64_t)(3 + 2 * i) * n_env + e]);
+        }
+        const bool in_range = sw::track_angle_range<N>(0.0, th) < sw::kAngleLimit;
+        double r;
+        (void)sw::euler_step<N>(C, gdx, gdy, th, thd, u, r);
+        double q = (gdx - rx) * (gdx - rx);
+        q = __builtin_fma(gdy - ry, gdy - ry, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            q = __builtin_fma(th[i] - rth[i], th[i] - rth[i], q);
+            q = __builtin_fma(thd[i] - rthd[i], thd[i] - rthd[i], q);
+        }
+        dist = in_range ? sqrt(q) : __builtin_nan("");
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) dist += __shfl_down(dist, off, kWave);
+    if (threadIdx.x % kWave == 0) wsum[threadIdx.x / kWave] = dist;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wsum[0];
+#pragma unroll
+        for (int w = 1; w < kStepBlock / kWave; ++w) t += wsum[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
 template <int N, bool TWIN>
 __global__ void __launch_bounds__(kStepBlock)
 accel_kernel(sw::Consts C, sw::TwinConsts T, int64_t n_env, const double *__restrict__ sin_,
@@ -2233,6 +2289,31 @@ int sw_step_f64(const sw_params *p, int64_t n_env, const double *state_in, const
     }
     return launch_status();
 }
+
+int sw_step_residual_f64(const sw_params *p, int64_t n_env, const double *state, const double *action,
+                         const double *next_ref, double *partial, void *stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (is_twin(p)) return SW_ERR_PARAM;          // the estimator's objective is defined on the Gym model
+    if (n_env < 0) return SW_ERR_SIZE;
+    if (n_env == 0) return SW_OK;
+    if (!state || !action || !next_ref || !partial) return SW_ERR_NULL;
+    const sw::Consts C = make_consts(p);
+    const unsigned grid = (unsigned)((n_env + kStepBlock - 1) / kStepBlock);
+    const int d = 2 * p->n + 2;
+    const bool nt = n_env * (int64_t)(8 * (2 * d + p->n)) > kStepStreamBytes;
+    if (nt) {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_residual_kernel<NN, true>), dim3(grid), dim3(kStepBlock), 0,
+                                               (hipStream_t)stream, C, n_env, state, action, next_ref, partial));
+    } else {
+        SW_DISPATCH_N(p->n, hipLaunchKernelGGL((step_residual_kernel<NN, false>), dim3(grid), dim3(kStepBlock), 0,
+                                               (hipStream_t)stream, C, n_env, state, action, next_ref, partial));
+    }
+    return launch_status();
+}
+
+int64_t sw_step_residual_blocks(int64_t n_env) { return n_env <= 0 ? 0 : (n_env + kStepBlock - 1) / kStepBlock; }
 
 int sw_accel_f64(const sw_params *p, int64_t n_env, const double *state, const double *action,
                  double *gdd, double *tdd, void *stream)

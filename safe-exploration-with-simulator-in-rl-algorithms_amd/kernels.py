@@ -44,6 +44,26 @@ def step(p: SwParams, state, action, out=None, reward=None, status=None):
     return out, reward
 
 
+def step_residual_blocks(n_transitions: int) -> int:
+    return int(load().sw_step_residual_blocks(int(n_transitions)))
+
+
+def step_residual(p: SwParams, state, action, next_ref, partial=None):
+    """Estimator.I's inner sum (ars/estimator.py:36-62) in one pass: per-workgroup sums of
+    || step(state, action) - next_ref ||_2 over the transitions (SoA [d, T], [m, T], [d, T]); their sum is I(x).
+    The simulated next states are never written (sw_step_residual_f64)."""
+    require_gpu()
+    T = state.shape[1]
+    _want(state, "state", (p.d, T))
+    _want(action, "action", (p.m, T))
+    _want(next_ref, "next_ref", (p.d, T))
+    nb = int(load().sw_step_residual_blocks(T))
+    partial = _f64((nb,), state.device) if partial is None else _want(partial, "partial", (nb,))
+    check(load().sw_step_residual_f64(ctypes.byref(p), T, ptr(state), ptr(action), ptr(next_ref), ptr(partial),
+                                      stream_ptr()), "sw_step_residual_f64")
+    return partial
+
+
 class StepPlan(object):
     """A pre-bound sw_step_f64 launch: all argument conversion is done once, `launch()` is a
     single foreign call (the per-launch Python overhead of `step()` is larger than the 8192-env

@@ -961,3 +961,38 @@ def test_fused_safe_rollouts_vs_oracle_every_chain_length(sw, n):
                 assert int(first[r]) == f_ref, (n, kind, index, sim_thresh, r, int(first[r]), f_ref)
                 taken = sto[:f_ref]
                 assert int(viol[r]) == int(sum(cost(ob) > real_thresh for ob in taken))
+
+
+@pytest.mark.parametrize("n", [2, 3, 6])
+def test_step_residual_is_the_step_then_the_distance(sw, n):
+    """sw_step_residual_f64 (Estimator.I's inner sum in one pass, ars/estimator.py:36-62) against the two-kernel form:
+    sw_step_f64, then the per-transition Euclidean distance to the stored next state -- and against the ORACLE's step
+    for the distances themselves; ragged size, fixed-order partial sums (bit-reproducible), argument checks."""
+    rs = np.random.RandomState(40 + n)
+    T, d, m = 1000, 2 * n + 2, n - 1
+    st = np.empty((T, d))
+    st[:, 0:2] = rs.uniform(-0.5, 0.5, (T, 2))
+    st[:, 2::2] = rs.uniform(-np.pi, np.pi, (T, n))
+    st[:, 3::2] = rs.uniform(-2, 2, (T, n))
+    ac = rs.uniform(-5, 5, (T, m))
+    op = oracle.OracleParams.make(n, 0.9, 1.1, 9.5, 1e-3)
+    nxt_true, _ = oracle.step_batch(op, st, ac)
+    stored = nxt_true + rs.normal(0, 1e-3, nxt_true.shape)          # a store recorded with other parameters
+    p = sw.SwParams.make(n, 0.9, 1.1, 9.5, 1e-3)
+    S, A, Nx = soa(st), soa(ac), soa(stored)
+    part = sw.kernels.step_residual(p, S, A, Nx)
+    assert part.shape == (sw.kernels.step_residual_blocks(T),) == (4,)
+    sim, _ = sw.kernels.step(p, S, A)
+    two_pass = torch.linalg.vector_norm(sim - Nx, ord=2, dim=0)
+    ref_dist = np.linalg.norm(nxt_true - stored, axis=1)
+    assert abs(float(part.sum()) - float(two_pass.sum())) <= 1e-12 * float(two_pass.sum())
+    assert abs(float(part.sum()) - ref_dist.sum()) <= 1e-9 * ref_dist.sum()
+    for b in range(4):                                               # workgroup b owns transitions [256 b, 256 (b + 1))
+        assert abs(float(part[b]) - float(two_pass[256 * b:256 * (b + 1)].sum())) <= 1e-12 * float(part[b])
+    assert torch.equal(part, sw.kernels.step_residual(p, S, A, Nx))   # fixed order: same bits
+    # exact zero when the store was recorded with the same parameters by the same kernel
+    assert float(sw.kernels.step_residual(p, S, A, sim).sum()) == 0.0
+    with pytest.raises(sw.SwimmerHipError):
+        sw.kernels.step_residual(sw.SwParams.make(n, flags=sw._lib.FLAG_MODEL_TWIN), S, A, Nx)
+    e = torch.empty((d, 0), dtype=torch.float64, device="cuda:0")
+    assert sw.kernels.step_residual(p, e, torch.empty((m, 0), dtype=torch.float64, device="cuda:0"), e).numel() == 0
