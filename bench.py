@@ -473,8 +473,11 @@ def aux_next_rows(sw, torch, device, n=3, H=1000, directions=512):
     out["estimator_objective"] = {"transitions": T, "us_per_evaluation": dt * 1e6,
                                   "us_mean": sum(samples) / len(samples) * 1e6, "us_max": max(samples) * 1e6,
                                   "transitions_per_s": T / dt,
-                                  "note": "Estimator.I(x): one step-kernel launch over every stored transition "
-                                          "of a device-resident store + norm reduction + .item()"}
+                                  "note": "Estimator.I(x): ONE launch that steps every stored transition of a "
+                                          "device-resident store and compares it with its stored next state "
+                                          "(sw_step_residual_f64, 144 B per transition) + the sum of its per-workgroup "
+                                          "partials + .item()",
+                                  "algorithmic_GBps": T * (16 * (2 * n + 2) + 8 * (n - 1)) / dt / 1e9}
     del est, agent
     # f-3: ARS V1 and the true top-b truncation (safe_ars semantics) as options of the same loop;
     # f-4: checkpoint save / load of a running agent
