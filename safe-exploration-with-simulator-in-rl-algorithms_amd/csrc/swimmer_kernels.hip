@@ -1860,35 +1860,6 @@ __device__ __forceinline__ bool rank_used_global(const GatherView &g, int32_t n_
     return rank < top_b;
 }
 
-// Top-b selection in LDS: flag[i] = (rank of direction i by max(r+, r-), ties to the higher index) < top_b.  Every
-// thread keeps the keys of ITS Q directions in registers and walks the N keys ONCE for all of them: per j one pair of
-// broadcast LDS reads and one max, shared by the thread's directions (the first version re-read and re-maximised the
-// whole list once per direction: ~25 us at N = 512 on the critical path between two rollout launches).
-template <int BLOCK, int Q>
-__device__ __forceinline__ void topb_rank_pass(const double *rp_s, const double *rm_s, unsigned char *flag,
-                                               int32_t n_dir, int64_t top_b)
-{
-    double ki[Q];
-    int32_t rank[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int32_t i = threadIdx.x + q * BLOCK;
-        ki[q] = (i < n_dir) ? fmax(rp_s[i], rm_s[i]) : 0.0;
-        rank[q] = 0;
-    }
-    for (int32_t j = 0; j < n_dir; ++j) {
-        const double kj = fmax(rp_s[j], rm_s[j]);
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-            rank[q] += (kj > ki[q]) || (kj == ki[q] && j > (int32_t)threadIdx.x + q * BLOCK);
-    }
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int32_t i = threadIdx.x + q * BLOCK;
-        if (i < n_dir) flag[i] = rank[q] < top_b;
-    }
-}
-
 // grid = m*d + 1 workgroups.  Workgroup e < m*d updates policy entry e; the last one merges
 // the V2 statistics.  The kernel sits on the critical path between two rollout launches and
 // is pure latency, so every workgroup first pulls what it needs with ONE round of loads (the
@@ -1926,13 +1897,15 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
             }
             __syncthreads();
             if (select) {
-                // rank of every direction by max(r+, r-), ties to the higher index (topb_rank_pass)
-                const int32_t per = (n_dir + BLOCK - 1) / BLOCK;     // directions per thread (wave-uniform)
-                if (per <= 1) topb_rank_pass<BLOCK, 1>(rp_s, rm_s, flag, n_dir, top_b);
-                else if (per <= 2) topb_rank_pass<BLOCK, 2>(rp_s, rm_s, flag, n_dir, top_b);
-                else if (per <= 4) topb_rank_pass<BLOCK, 4>(rp_s, rm_s, flag, n_dir, top_b);
-                else if (per <= 8) topb_rank_pass<BLOCK, 8>(rp_s, rm_s, flag, n_dir, top_b);
-                else topb_rank_pass<BLOCK, kMaxPer>(rp_s, rm_s, flag, n_dir, top_b);
+                for (int32_t i = threadIdx.x; i < n_dir; i += BLOCK) {
+                    const double ki = fmax(rp_s[i], rm_s[i]);
+                    int32_t rank = 0;
+                    for (int32_t j = 0; j < n_dir; ++j) {
+                        const double kj = fmax(rp_s[j], rm_s[j]);
+                        rank += (kj > ki) || (kj == ki && j > i);
+                    }
+                    flag[i] = rank < top_b;
+                }
                 __syncthreads();
             }
         }
