@@ -102,3 +102,53 @@ def test_world_size_mismatch_is_refused():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+
+
+STRONG_N6_RANK_SCRIPT = textwrap.dedent("""
+    # Stand-in for one rank of `bench.py --gpus 8 --scaling strong --segments 6` on CPU (no GPU here): the real flag
+    # parser, the real shard arithmetic and packed-segment layout of ars/sharding.py, the exchange over gloo -- only
+    # the kernels are replaced by rank-tagged numbers.
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import bench
+    from swimmer_amd.ars.sharding import all_gather_segments, returns_from_segments, segment_len, shard_bounds
+    args = bench.parse(sys.argv[1:])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert world == args.gpus
+    dist.init_process_group("gloo")
+    n, N = args.segments, (args.total_directions if args.scaling == "strong" else args.directions * world)
+    d = 2 * n + 2
+    lo, hi, chunk = shard_bounds(N, rank, world)
+    rows_chunk = -(-2 * chunk // 16)
+    L = segment_len(chunk, rows_chunk, 2 * d)
+    send = torch.zeros(L, dtype=torch.float64)
+    send[:2 * (hi - lo)] = torch.arange(2 * lo, 2 * hi, dtype=torch.float64)      # "returns": their own global index
+    send[2 * chunk:] = float(rank + 1)                                             # "moment rows"
+    gathered = torch.zeros(world * L, dtype=torch.float64)
+    all_gather_segments(send, gathered, world)
+    rets = returns_from_segments(gathered, N, world, chunk)
+    ok = torch.equal(rets, torch.arange(2 * N, dtype=torch.float64))
+    moments_ok = all(bool((gathered[r * L + 2 * chunk:(r + 1) * L] == r + 1.0).all()) for r in range(world))
+    flag = torch.tensor([1.0 if (ok and moments_ok) else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"ranks_seen": world, "scaling": args.scaling, "segments": n, "directions_total": N,
+                          "directions_per_rank": chunk, "segment_doubles": L, "all_ranks_ok": bool(flag.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_eight_rank_strong_scaling_of_the_six_segment_config_rehearsed_on_cpu(tmp_path):
+    """`bench.py --gpus 8 --scaling strong --segments 6` (configs[4] as stated) rehearsed WITHOUT GPUs: bench's own
+    launcher spawns eight ranks that parse the real flags, shard 2048 directions with the real helpers, exchange their
+    packed [returns | moment rows] segments over gloo and check the gathered layout on every rank (the GPU rehearsal
+    with the real kernels is tests/test_bench_rehearsal.py, four ranks on one card)."""
+    out = _run_launcher(tmp_path, STRONG_N6_RANK_SCRIPT, 8, ["--gpus", "8", "--scaling", "strong", "--segments", "6"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"ranks_seen": 8, "scaling": "strong", "segments": 6, "directions_total": 2048,
+                   "directions_per_rank": 256, "segment_doubles": 2 * 256 + 32 * 28, "all_ranks_ok": True}
