@@ -36,6 +36,7 @@ class Estimator(object):
         self.device = torch.device(device)
         self._cache = None
         self._partial = None
+        self._jcache = None
 
     def convert_to_env_param(self, x):
         d = dataclasses.asdict(self.guess_param)
@@ -110,21 +111,23 @@ class Estimator(object):
         return float(self._partial.sum().item())
 
     def J(self, x):
-        """Deprecated objective of the reference (estimator.py:64-87): whole-rollout distance."""
+        """Deprecated objective of the reference (estimator.py:64-87): whole-rollout distance.  ONE launch of the
+        rollout kernels over every selected rollout (the reference re-runs them one after the other), then the
+        per-step and per-rollout norms on the device."""
         require_gpu()
         p = self._params(x)
-        dists = []
-        for k in self.subset:
-            P = torch.as_tensor(np.asarray(self.database.policies[k], dtype=np.float64)[None],
-                                device=self.device).contiguous()
-            real = torch.as_tensor(np.asarray(self.database.trajectories[k], dtype=np.float64),
-                                   device=self.device)
-            H = real.shape[0]
-            traj = torch.empty((H, p.d, 1), dtype=torch.float64, device=self.device)
-            kernels.rollout(p, H, P, traj=traj)
-            per_step = torch.linalg.vector_norm(traj[:, :, 0] - real, ord=2, dim=1)
-            dists.append(float((torch.linalg.vector_norm(per_step, ord=2) / H).item()))
-        return float(np.mean(dists))
+        if self._jcache is None:
+            P = np.stack([np.asarray(self.database.policies[k], dtype=np.float64) for k in self.subset])
+            real = np.stack([np.asarray(self.database.trajectories[k], dtype=np.float64) for k in self.subset])
+            self._jcache = (torch.as_tensor(P, device=self.device).contiguous(),
+                            torch.as_tensor(real, device=self.device).permute(1, 2, 0).contiguous())   # [H, d, K]
+        P, real = self._jcache
+        H, K = real.shape[0], real.shape[2]
+        traj = torch.empty((H, p.d, K), dtype=torch.float64, device=self.device)
+        kernels.rollout(p, H, P, traj=traj)
+        per_step = torch.linalg.vector_norm(traj - real, ord=2, dim=1)             # [H, K]
+        dists = torch.linalg.vector_norm(per_step, ord=2, dim=0) / H               # [K]
+        return float(dists.mean().item())
 
     def estimate_real_env_param(self):
         """CMA-ES over I(x) (estimator.py:89-110); needs the optional `cma` package."""
