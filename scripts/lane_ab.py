@@ -3,6 +3,10 @@ between library builds, and what the chip's power state does to the same launch.
 
   python scripts/lane_ab.py [libA.so libB.so ...]      (default: the in-tree build only)
 
+An older build to compare with (built in the container, travels to the GPU box with the snapshot; *.so is git-ignored):
+  mkdir -p /tmp/r2 scripts/ab && git archive f756c65 safe-exploration-with-simulator-in-rl-algorithms_amd/csrc include | tar -x -C /tmp/r2
+  (cd /tmp/r2/*/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC swimmer_kernels.hip host_rng.cpp -ldl -o $OLDPWD/scripts/ab/lib_r2.so)
+
 Raw ctypes on sw_rollout_f64 (same signature since ABI 2), so that a round-2 build can be loaded beside
 the current one in ONE process; the builds are timed interleaved (A B A B ...), every launch with its own
 HIP events, median reported.  Then, with the first library only: the same launch (i) after two seconds of
