@@ -107,12 +107,16 @@ class Basic_ARS(object):
                 state = torch.where(safe, nxt, state)                       # refused: stay (:150-151)
                 total += torch.where(safe, rew, torch.zeros_like(rew))
             states[t] = state
+        self._finish()
         return total.cpu().numpy(), states.permute(2, 0, 1).cpu().numpy()
 
     def _prepare(self, B, d, dev):
         pass
 
     def _after_real_step(self, nxt, safe):
+        pass
+
+    def _finish(self):
         pass
 
     def rollout(self, real_env, policy, H, render=False):
@@ -195,6 +199,7 @@ class Safe_ARS(Basic_ARS):
         self._p_sim = _params(self.sim_env)
         self._sim_next = torch.empty((d, B), dtype=torch.float64, device=dev)
         self._sim_rew = torch.empty(B, dtype=torch.float64, device=dev)
+        self._over = torch.zeros((), dtype=torch.int64, device=dev)
 
     def _cost_batch(self, obs):
         """cost over a [d, B] batch -> [B] tensor (one tensor call; per-swimmer calls if the callable refuses)."""
@@ -220,7 +225,8 @@ class Safe_ARS(Basic_ARS):
         return self._cost_batch(self._sim_next) <= self.sim_thresh
 
     def _after_real_step(self, nxt, safe):
-        over = (self._cost_batch(nxt) > self.real_thresh) & safe
-        n_over = int(over.sum().item())
-        if n_over:
-            self.real_violations += n_over
+        # counted on the device; read back once per batch (_finish), not once per step
+        self._over += ((self._cost_batch(nxt) > self.real_thresh) & safe).sum()
+
+    def _finish(self):
+        self.real_violations += int(self._over.item())

@@ -821,6 +821,14 @@ def test_fused_safe_rollouts_vs_reference(sw, golden):
     assert agent.first_refused.cpu().numpy().tolist() == g["rollout_first_refused"].tolist()
     R2, st2 = agent.rollouts(real, g["rollout_policies"], H, fused=False)          # lock-step path, same cost object
     assert np.abs(st2 - st).max() <= 1e-12 and np.abs(R2 - R).max() <= 1e-13
+    # real steps whose cost exceeds real_thresh (the reference prints one line each, :143-144) are COUNTED, by both
+    # paths alike: with a real threshold far below the simulator's some steps pass the gate and still violate
+    counts = []
+    for fused in (True, False):
+        a = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), 0.05, sim_thresh, sim)
+        a.rollouts(real, g["rollout_policies"], H, fused=fused)
+        counts.append(a.real_violations)
+    assert counts[0] == counts[1] > 0
     for tag in ("max3", "max6"):
         nn, HH = (int(v) for v in g[tag + "_cfg"])
         thr = [float(v) for v in g[tag + "_thresholds"]]
