@@ -1866,6 +1866,7 @@ __device__ __forceinline__ bool rank_used_global(const GatherView &g, int32_t n_
 // 2 n_dir returns and its delta column into LDS / registers; all moment rows in parallel) and
 // then only touches LDS: ~5 us instead of ~17 us for the load-then-use-per-pass version.
 constexpr int kUpdMaxDirs = kTopBMaxDirs;
+constexpr int kTopBSortDirs = 2048;   // top-b by a bitonic sort in LDS up to here, by ranking beyond
 
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -1896,7 +1897,54 @@ ars_update_kernel(int d, int md, int32_t n_dir, GatherView gv,
                 rm_s[i] = ret_at(gv, i, 1);
             }
             __syncthreads();
-            if (select) {
+            if (select && n_dir <= kTopBSortDirs) {
+                // Up to 2048 directions: a bitonic sort of (key, index) in LDS, best first -- key = max(r+, r-)
+                // descending, ties to the higher index, NaN keys first (np.argsort puts NaN last and the reference
+                // reverses it, ars_agent.py:105-108).  log2(P) (log2(P) + 1) / 2 compare-exchange stages of P / 2
+                // pairs each (45 stages at 512 directions: ~4 us) instead of N^2 / BLOCK comparisons per thread with
+                // the key list re-read for every direction (~25 us on the critical path between two rollout launches).
+                __shared__ double skey[kTopBSortDirs];
+                __shared__ uint16_t sidx[kTopBSortDirs];
+                uint32_t P2 = 2;
+                while (P2 < (uint32_t)n_dir) P2 <<= 1;
+                for (uint32_t i = threadIdx.x; i < P2; i += BLOCK) {
+                    double k = -HUGE_VAL;
+                    if (i < (uint32_t)n_dir) {
+                        // NOT fmax: Python's max(a, b) = (b > a) ? b : a (safe_ars / ars_agent sort_directions)
+                        const double a = rp_s[i], b = rm_s[i];
+                        k = (b > a) ? b : a;
+                        k = (k != k) ? HUGE_VAL : k;
+                    }
+                    skey[i] = k;
+                    sidx[i] = (uint16_t)i;
+                }
+                __syncthreads();
+                for (uint32_t k = 2; k <= P2; k <<= 1) {
+                    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                        for (uint32_t t = threadIdx.x; t < P2 / 2; t += BLOCK) {
+                            const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), hi = lo | j;
+                            const double ka = skey[lo], kb = skey[hi];
+                            const uint32_t ia = sidx[lo], ib = sidx[hi];
+                            // a goes before b?  padding (index >= n_dir) always goes last
+                            const bool a_first = (ia < (uint32_t)n_dir) &&
+                                                 ((ib >= (uint32_t)n_dir) || ka > kb || (ka == kb && ia > ib));
+                            const bool best_first = (lo & k) == 0;     // direction of this bitonic block
+                            if (a_first != best_first) {
+                                skey[lo] = kb;
+                                skey[hi] = ka;
+                                sidx[lo] = (uint16_t)ib;
+                                sidx[hi] = (uint16_t)ia;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (uint32_t pos = threadIdx.x; pos < P2; pos += BLOCK) {
+                    const uint32_t i = sidx[pos];
+                    if (i < (uint32_t)n_dir) flag[i] = (int64_t)pos < top_b;
+                }
+                __syncthreads();
+            } else if (select) {
                 for (int32_t i = threadIdx.x; i < n_dir; i += BLOCK) {
                     const double ki = fmax(rp_s[i], rm_s[i]);
                     int32_t rank = 0;

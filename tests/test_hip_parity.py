@@ -1004,3 +1004,31 @@ def test_step_residual_is_the_step_then_the_distance(sw, n):
         sw.kernels.step_residual(sw.SwParams.make(n, flags=sw._lib.FLAG_MODEL_TWIN), S, A, Nx)
     e = torch.empty((d, 0), dtype=torch.float64, device="cuda:0")
     assert sw.kernels.step_residual(p, e, torch.empty((m, 0), dtype=torch.float64, device="cuda:0"), e).numel() == 0
+
+
+@pytest.mark.parametrize("n_dir", [5, 17, 512, 700, 2048, 2049])
+def test_top_b_selection_with_ties_at_every_size(sw, n_dir):
+    """The update kernel's top-b selection (safe_ars/ars.py:41-42, :96: the best b directions by max(r+, r-)) against a
+    host computation, with MANY exact ties in the keys: sizes below / at / between powers of two (the bitonic sort in LDS
+    pads to one), at its limit (2048) and just beyond it (2049: the ranking loop).  Rule pinned since round 2: key
+    descending, ties to the higher index."""
+    rs = np.random.RandomState(n_dir)
+    p = sw.SwParams.make(3)
+    m, d = 2, 8
+    rets = rs.randint(-3, 4, 2 * n_dir).astype(np.float64) + 0.25 * rs.randint(0, 2, 2 * n_dir)   # few distinct values
+    deltas = 2 * rs.rand(n_dir, m, d) - 1
+    keys = np.maximum(rets[0::2], rets[1::2])
+    order = sorted(range(n_dir), key=lambda i: (keys[i], i), reverse=True)          # key desc, then index desc
+    for top_b in (1, 2, max(1, n_dir // 3), n_dir - 1):
+        used = order[:top_b]
+        ur = np.array([[rets[2 * i], rets[2 * i + 1]] for i in used])
+        sigma = ur.std()
+        if sigma == 0.0:
+            continue
+        grad = sum((rets[2 * i] - rets[2 * i + 1]) * deltas[i] for i in used) / (len(used) * sigma)
+        pol = torch.zeros((m, d), dtype=torch.float64, device="cuda:0")
+        sig = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+        sw.kernels.ars_update(p, torch.as_tensor(rets, device="cuda:0"), torch.as_tensor(deltas, device="cuda:0"), pol,
+                              alpha=0.01, b=float(n_dir), top_b=top_b, sigma_out=sig)
+        assert abs(float(sig) - sigma) <= 1e-13 * sigma, (n_dir, top_b)
+        assert np.abs(pol.cpu().numpy() - 0.01 * grad).max() <= 1e-12 * max(1.0, np.abs(grad).max()), (n_dir, top_b)
