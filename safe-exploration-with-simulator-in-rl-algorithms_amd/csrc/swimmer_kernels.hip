@@ -1586,6 +1586,173 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
 }
 
 // ------------------------------------------------------------------------------------
+// The safe-exploration gate (safe_rollout_kernel above has the semantics) for n = 3 in the MIRROR-QUAD form of
+// rollout_oct3_kernel: two quads of eight lanes per rollout, lane roles, reduced angles.  The geometry of a step
+// (sin / cos, cos(th_i - th_k), ...) depends on the angles only and is therefore SHARED by the simulator's look-ahead
+// and the real step: per step one geometry, two `oct3_dynamics` (simulator constants on copies of Gdot / thetadot,
+// real constants), the cost of the simulated next state on the lanes that own the observed quantity, one AND over
+// the rollout's eight lanes (three DPP-ANDs: the two mirror quads differ by rounding, the decision must not), and
+// the real step committed through selects.  ~190 instructions per env-step instead of ~640 in the lane form.
+// A refused rollout keeps recomputing the same refused step (its state no longer changes), as in the reference.
+__device__ __forceinline__ double oct_sel(bool take, double a, double b) { return take ? a : b; }
+
+template <bool TRAJ, bool VIOL>
+__global__ void __launch_bounds__(kOctBlock)
+safe_rollout_oct3_kernel(sw::Consts Cr, sw::Consts Cs, double tq_ratio, int64_t n_roll, int32_t H,
+                         const double *__restrict__ policies, int32_t cost_kind, int32_t cost_index,
+                         double sim_thresh, double real_thresh, double *__restrict__ returns,
+                         double *__restrict__ traj, int32_t *__restrict__ first_refused,
+                         int32_t *__restrict__ violations, int32_t *__restrict__ status)
+{
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int D = 8, M = 2;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int q = lane & 3;
+    const int seg = (q == 3) ? 0 : q;              // lane 3 of a quad mirrors lane 0
+    const bool cosine = (lane & 8) != 0;           // quad B: cosine / Gdot_y roles
+    const int64_t r_raw = (int64_t)blockIdx.x * kMomGroup + wave * 8 + (lane >> 4) * 2 + ((lane >> 2) & 1);
+    const bool valid = r_raw < n_roll;
+    const int64_t r = valid ? r_raw : n_roll - 1;  // surplus rollouts recompute the last one
+    const sw::OctLane Or = sw::oct3_lane(Cr, seg, cosine), Os = sw::oct3_lane(Cs, seg, cosine);
+    const int cth = 2 + 2 * seg, cthd = 3 + 2 * seg;
+    const int seg1 = (seg + 1) % 3, seg2 = (seg + 2) % 3;
+    const int cols[D] = {0, 1, cth, cthd, 2 + 2 * seg1, 3 + 2 * seg1, 2 + 2 * seg2, 3 + 2 * seg2};
+    double V[D], nbias;
+    load_policy_row<D, M, false>(policies + r * (M * D), nullptr, 1.0, 0.0, nullptr, nullptr, Cr.c12, seg, cols, V,
+                                 nbias);
+    const double VPu = cosine ? V[1] : V[0], VPv = cosine ? V[0] : V[1];
+
+    // which quantity of the (simulated, resp. real) next state this lane contributes to the cost: obs =
+    // [Gdx (quad A's Pu), Gdy (quad B's Pu), th_1, thd_1, ...] -- quad A's segment lanes own (theta_i, thetadot_i)
+    const bool segA = !cosine && q < 3;
+    bool own_pu = false, own_th = false, own_thd = false;
+    if (cost_kind == SW_COST_MAX_ABS_THETADOT) {
+        own_thd = segA;
+    } else if (cost_index == 0) {
+        own_pu = !cosine && q == 0;
+    } else if (cost_index == 1) {
+        own_pu = cosine && q == 0;
+    } else {
+        const bool mine = segA && seg == ((cost_index - 2) >> 1);
+        own_thd = mine && ((cost_index - 2) & 1);
+        own_th = mine && !((cost_index - 2) & 1);
+    }
+    const bool owner = own_pu || own_th || own_thd;
+
+    double th = kHalfPi, thd = 0.0, Pu = 0.0, Pv = 0.0;       // real_env.reset() (:133)
+    const uint32_t kDrop = 0xfffffff0u;
+    const bool rec = !cosine && q < 3;
+    const uint32_t off_th = rec ? (uint32_t)(((int64_t)cth * n_roll + r) * 8) : kDrop;
+    const uint32_t off_thd = rec ? (uint32_t)(((int64_t)cthd * n_roll + r) * 8) : kDrop;
+    const uint32_t off_g = (q == 0) ? (uint32_t)(((int64_t)(cosine ? 1 : 0) * n_roll + r) * 8) : kDrop;
+    const uint32_t slab = (uint32_t)(D * n_roll * 8);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        traj, 0, TRAJ ? (int)(uint32_t)((int64_t)H * slab) : 0, 0x00020000);
+    uint32_t soff = 0;
+    auto store_cell = [&](double v, uint32_t voff) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        union { double d; v2i i; } u;
+        u.d = v;
+        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
+    };
+    const int designation = cosine ? 1 : 0;
+    double thmax = 0.0, det = 1.0;
+    sw::OctTrig A;
+    A.r = th;
+    A.kd = 0.0;
+    sw::oct3_renorm(A, designation, thmax);
+    double ret = 0.0;
+    int32_t taken = 0, over = 0;
+    bool alive = true;                                    // once refused, always refused
+    double w1 = 0.0, w2 = 0.0;
+    double Th = __builtin_fma(V[2], th, nbias);
+    Th = __builtin_fma(V[4], sw::dpp_f64<sw::kDppNext1>(th), Th);
+    Th = __builtin_fma(V[6], sw::dpp_f64<sw::kDppNext2>(th), Th);
+    const double hV2 = Cr.h * V[2], hV4 = Cr.h * V[4], hV6 = Cr.h * V[6];
+    sw::OctGeo G = sw::oct3_geometry(A), Gn;
+    double magic = 6755399441055744.0;
+    asm volatile("" : "+v"(magic));
+    // AND of a per-lane flag over the eight lanes of this lane's rollout (two rotations inside the quad, then the
+    // mirror quad eight lanes away)
+    auto all_of_rollout = [&](bool f) -> bool {
+        int v = f ? 1 : 0;
+        v &= __builtin_amdgcn_mov_dpp(v, 1 | (2 << 2) | (3 << 4) | (0 << 6), 0xf, 0xf, true);   // [1,2,3,0]
+        v &= __builtin_amdgcn_mov_dpp(v, 2 | (3 << 2) | (0 << 4) | (1 << 6), 0xf, 0xf, true);   // [2,3,0,1]
+        v &= __builtin_amdgcn_mov_dpp(v, sw::kDppRowRor8, 0xf, 0xf, true);
+        return v != 0;
+    };
+    auto one_step = [&](const sw::OctGeo &Gc, sw::OctGeo &Gx) {
+        double tq = __builtin_fma(VPu, Pu, Th);
+        tq = __builtin_fma(VPv, Pv, tq);
+        tq = __builtin_fma(V[3], thd, tq);
+        tq = __builtin_fma(V[5], w1, tq);
+        tq = __builtin_fma(V[7], w2, tq);
+        // the simulator's look-ahead from the real state (:120-121): same geometry, its own constants, copies
+        double Pus = Pu, thds = thd;
+        (void)sw::oct3_dynamics(Cs, Os, Gc, Pus, Pv, thds, w1, w2, tq * tq_ratio);
+        const double ths = __builtin_fma(Cs.h, thd, th);
+        const double vs = own_thd ? thds : (own_th ? ths : Pus);
+        const bool safe = all_of_rollout(!owner || (fabs(vs) <= sim_thresh)) && alive;     // :122, NaN refuses
+        alive = safe;
+        // the real step on copies, committed where the gate is open (:142)
+        double Pur = Pu, thdr = thd;
+        const double det_new = sw::oct3_dynamics(Cr, Or, Gc, Pur, Pv, thdr, w1, w2, tq);
+        const double r_new = __builtin_fma(Cr.h, thd, A.r);
+        double Th_new = __builtin_fma(hV2, thd, Th);
+        Th_new = __builtin_fma(hV4, w1, Th_new);
+        Th_new = __builtin_fma(hV6, w2, Th_new);
+        A.r = oct_sel(safe, r_new, A.r);
+        const unsigned long long outside = sw::oct3_range_test(A.r);
+        Th = oct_sel(safe, Th_new, Th);
+        thd = oct_sel(safe, thdr, thd);
+        Pu = oct_sel(safe, Pur, Pu);
+        det = oct_sel(safe, det_new, det);
+        sw::oct3_keep_reduced(A, thmax, magic, designation, outside);
+        th = __builtin_fma(A.kd, sw::kPio2Hi, A.r);
+        Gx = sw::oct3_geometry(A);
+        ret += oct_sel(safe, Pu, 0.0);
+        taken += safe ? 1 : 0;
+        if (VIOL) {
+            const double vr = own_thd ? thd : (own_th ? th : Pu);
+            // cost > real_thresh (:143): any owner lane over the threshold (max |thetadot_i|), on a step that was taken
+            const bool fine = all_of_rollout(!owner || !(fabs(vr) > real_thresh));
+            over += (safe && !fine) ? 1 : 0;
+        }
+        if (TRAJ) {
+            store_cell(th, off_th);
+            store_cell(thd, off_thd);
+            store_cell(Pu, off_g);
+            soff += slab;
+        }
+        w1 = sw::dpp_f64<sw::kDppNext1>(thd);
+        w2 = sw::dpp_f64<sw::kDppNext2>(thd);
+        Pv = sw::dpp_row_f64<sw::kDppRowRor8>(Pu);
+    };
+    int32_t t = 0;
+    for (; t + 2 <= H; t += 2) {
+        one_step(G, Gn);
+        one_step(Gn, G);
+    }
+    if (t < H) one_step(G, Gn);
+    thmax = fmax(thmax, fabs(th));
+
+    int code = ((det > 0.0) ? 0 : SW_STATUS_SINGULAR) |
+               ((isfinite(th) && isfinite(thd) && isfinite(Pu) && isfinite(Pv)) ? 0 : SW_STATUS_NONFINITE) |
+               ((thmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
+    code |= __builtin_amdgcn_mov_dpp(code, sw::kDppNext1, 0xf, 0xf, true) |
+            __builtin_amdgcn_mov_dpp(code, sw::kDppNext2, 0xf, 0xf, true);
+    code |= __builtin_amdgcn_mov_dpp(code, sw::kDppRowRor8, 0xf, 0xf, true);
+    const double ret_other = sw::dpp_row_f64<sw::kDppRowRor8>(ret);   // on A: sum of the taken steps' Gdot_y
+    if (valid && !cosine && q == 0) {
+        const double total = __builtin_fma(Cr.dirx, ret, Cr.diry * ret_other);
+        returns[r] = (code & SW_STATUS_RANGE) ? __builtin_nan("") : total;
+        if (first_refused) first_refused[r] = taken;      // the gate never re-opens: steps taken = first refused step
+        if (violations) violations[r] = over;
+        if (status) status[r] = code;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // n = 4..8, one segment per lane, one rollout per 16-lane DPP row (swimmer_row.h).
 // 256-thread workgroups: 4 waves x 4 rows = 16 rollouts = one V2 moment row.
 // Two waves per SIMD must fit for n <= 6 (256 registers each): the covariance workgroups that ride along
@@ -2454,6 +2621,22 @@ int sw_safe_rollouts_f64(const sw_params *real, const sw_params *sim, int64_t n_
     if (n_roll == 0) return SW_OK;
     if (!policies || !returns) return SW_ERR_NULL;
     const sw::Consts Cr = make_consts(real), Cs = make_consts(sim);
+    if (use_oct3(real, n_roll, H, traj != nullptr)) {
+        // n = 3, up to 8192 rollouts: the mirror-quad form (one geometry, two dynamics per env-step)
+        const unsigned ogrid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+        const double tq_ratio = Cs.c12 / Cr.c12;
+#define SW_LAUNCH_SAFE_OCT(TRAJ, VIOL)                                                                          \
+    hipLaunchKernelGGL((safe_rollout_oct3_kernel<TRAJ, VIOL>), dim3(ogrid), dim3(kOctBlock), 0,                 \
+                       (hipStream_t)stream, Cr, Cs, tq_ratio, n_roll, H, policies, cost_kind, cost_index,       \
+                       sim_thresh, real_thresh, returns, traj, first_refused, violations, status)
+        if (traj) {
+            if (violations) SW_LAUNCH_SAFE_OCT(true, true); else SW_LAUNCH_SAFE_OCT(true, false);
+        } else {
+            if (violations) SW_LAUNCH_SAFE_OCT(false, true); else SW_LAUNCH_SAFE_OCT(false, false);
+        }
+#undef SW_LAUNCH_SAFE_OCT
+        return launch_status();
+    }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
     SW_DISPATCH_N(real->n, hipLaunchKernelGGL((safe_rollout_kernel<NN>), dim3(grid), dim3(kRollBlock), 0,
                                               (hipStream_t)stream, Cr, Cs, n_roll, H, policies, cost_kind,

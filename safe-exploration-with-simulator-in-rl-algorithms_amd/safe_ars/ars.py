@@ -25,7 +25,8 @@ import numpy as np
 import torch
 
 from .. import kernels
-from .._lib import (COST_ABS_OBS, COST_MAX_ABS_THETADOT, SwParams, numpy_global_uniform_pm1, require_gpu)
+from .._lib import (COST_ABS_OBS, COST_MAX_ABS_THETADOT, SwParams, kernel_flags, numpy_global_uniform_pm1,
+                    require_gpu)
 
 
 class NativeCost(object):
@@ -164,8 +165,11 @@ class Basic_ARS(object):
 class Safe_ARS(Basic_ARS):
     """safe_ars/ars.py:101-153 -- every real step gated by a one-step look-ahead in `sim_env`."""
 
-    def __init__(self, cost, real_threshold, sim_threshold, sim_env):
+    def __init__(self, cost, real_threshold, sim_threshold, sim_env, rollout_kernel="auto"):
+        """`rollout_kernel` (not in the reference): "auto" | "lane" | "quad" -- which form of the fused gate kernel a
+        native cost runs on (auto: the mirror-quad form for n = 3 up to 8192 rollouts, one rollout per lane otherwise)."""
         self.cost = cost
+        self._flags = kernel_flags(rollout_kernel)
         self.real_thresh = real_threshold
         self.sim_thresh = sim_threshold
         self.sim_env = sim_env
@@ -185,6 +189,7 @@ class Safe_ARS(Basic_ARS):
         require_gpu()
         dev = getattr(real_env, "device", torch.device("cuda:0"))
         p_real, p_sim = _params(real_env), _params(self.sim_env)
+        p_real.flags = self._flags
         P = torch.as_tensor(np.ascontiguousarray(policies, dtype=np.float64), device=dev)
         B, d = P.shape[0], p_real.d
         traj = torch.empty((H, d, B), dtype=torch.float64, device=dev)

@@ -801,7 +801,8 @@ def test_safe_ars_gate_vs_reference(sw, golden):
     assert np.abs(states[-2 * N:] - g["train_last_states"]).max() <= 1e-9
 
 
-def test_fused_safe_rollouts_vs_reference(sw, golden):
+@pytest.mark.parametrize("form", ["auto", "lane"])
+def test_fused_safe_rollouts_vs_reference(sw, golden, form):
     """The gated rollout as ONE launch (sw_safe_rollouts_f64: action, simulator look-ahead, cost, gate and real step in
     registers, one rollout per lane) for the native costs: |obs[3]| against the fixtures of the test above, and the
     reference experiment's own cost max_i |thetadot_i| (safe_ars/experiment.py:45) at n = 3 and n = 6 -- against
@@ -815,7 +816,9 @@ def test_fused_safe_rollouts_vs_reference(sw, golden):
         return (sw.SwimmerEnv(n=nn, l_i=rp[0], m_i=rp[1], k=rp[2], h=rp[3]),
                 sw.SwimmerEnv(n=nn, l_i=sp[0], m_i=sp[1], k=sp[2], h=sp[3]))
     real, sim = envs(n)
-    agent = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), real_thresh, sim_thresh, sim)
+    # form "auto": n = 3 runs on the mirror-quad gate kernel (safe_rollout_oct3_kernel), n = 6 on the lane form;
+    # form "lane": everything on the one-rollout-per-lane kernel
+    agent = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), real_thresh, sim_thresh, sim, rollout_kernel=form)
     R, st = agent.rollouts(real, g["rollout_policies"], H)                        # fused: one launch
     assert np.abs(st - g["rollout_states"]).max() <= 1e-10 and np.abs(R - g["rollout_returns"]).max() <= 1e-12
     assert agent.first_refused.cpu().numpy().tolist() == g["rollout_first_refused"].tolist()
@@ -825,7 +828,7 @@ def test_fused_safe_rollouts_vs_reference(sw, golden):
     # paths alike: with a real threshold far below the simulator's some steps pass the gate and still violate
     counts = []
     for fused in (True, False):
-        a = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), 0.05, sim_thresh, sim)
+        a = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), 0.05, sim_thresh, sim, rollout_kernel=form)
         a.rollouts(real, g["rollout_policies"], H, fused=fused)
         counts.append(a.real_violations)
     assert counts[0] == counts[1] > 0
@@ -833,7 +836,7 @@ def test_fused_safe_rollouts_vs_reference(sw, golden):
         nn, HH = (int(v) for v in g[tag + "_cfg"])
         thr = [float(v) for v in g[tag + "_thresholds"]]
         real, sim = envs(nn)
-        a = sw.safe_ars.Safe_ARS(sw.safe_ars.MaxAbsThetaDot(), thr[1], thr[0], sim)
+        a = sw.safe_ars.Safe_ARS(sw.safe_ars.MaxAbsThetaDot(), thr[1], thr[0], sim, rollout_kernel=form)
         R, st = a.rollouts(real, g[tag + "_policies"], HH)
         assert np.abs(st - g[tag + "_states"]).max() <= 1e-10 and np.abs(R - g[tag + "_returns"]).max() <= 1e-12
         assert a.first_refused.cpu().numpy().tolist() == g[tag + "_first_refused"].tolist()
@@ -848,7 +851,7 @@ def test_fused_safe_rollouts_vs_reference(sw, golden):
     alpha, nu = (float(v) for v in g["train_hyper"])
     real, sim = envs(n)
     np.random.seed(seed)
-    a = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), real_thresh, sim_thresh, sim)
+    a = sw.safe_ars.Safe_ARS(sw.safe_ars.AbsObs(3), real_thresh, sim_thresh, sim, rollout_kernel=form)
     curve, states = a.train(iters, real, N, b, alpha, nu, Ht)
     assert np.abs(a.policy - g["train_policies"][iters - 1]).max() <= 1e-9
     assert np.abs(curve - g["train_curve"]).max() <= 1e-12
@@ -942,9 +945,11 @@ def test_fused_safe_rollouts_vs_oracle_every_chain_length(sw, n):
     s_real, s_sim = sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3), sw.SwParams.make(n, 1.0, 1.0, 10.0, 1e-3)
     costs = ((sw._lib.COST_ABS_OBS, 3, lambda ob: abs(ob[3])),
              (sw._lib.COST_ABS_OBS, 2 * n, lambda ob: abs(ob[2 * n])),                 # |theta_n|: starts at pi/2
-             (sw._lib.COST_MAX_ABS_THETADOT, 0, lambda ob: np.max([abs(ob[3 + 2 * i]) for i in range(n)])))
+             (sw._lib.COST_MAX_ABS_THETADOT, 0, lambda ob: np.max([abs(ob[3 + 2 * i]) for i in range(n)])),
+             (sw._lib.COST_ABS_OBS, 0, lambda ob: abs(ob[0])),                         # |Gdot_x| (quad A's lanes at n = 3)
+             (sw._lib.COST_ABS_OBS, 1, lambda ob: abs(ob[1])))                         # |Gdot_y| (quad B's)
     for kind, index, cost in costs:
-        for sim_thresh, real_thresh in ((0.25, 0.2), (-1.0, 0.0), (1.6, 1.58)):
+        for sim_thresh, real_thresh in ((0.25, 0.2), (-1.0, 0.0), (1.6, 1.58), (0.003, 0.002)):
             traj = torch.empty((H, d, R), dtype=torch.float64, device="cuda:0")
             first = torch.empty(R, dtype=torch.int32, device="cuda:0")
             viol = torch.empty(R, dtype=torch.int32, device="cuda:0")
