@@ -563,23 +563,28 @@ def aux_safe_gate(sw, torch, device, n=3, n_roll=1024, H=1000):
     traj = torch.empty((H, d, n_roll), dtype=torch.float64, device=device)
     first = torch.empty(n_roll, dtype=torch.int32, device=device)
 
-    def go():
-        sw.kernels.safe_rollouts(p_real, p_sim, H, pol, sw._lib.COST_MAX_ABS_THETADOT, 0, 1e9, 1e9, traj=traj,
-                                 first_refused=first)
-    for _ in range(3):
-        go()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
-    for a, b in ev:
-        a.record()
-        go()
-        b.record()
-    torch.cuda.synchronize()
-    ms = sorted(a.elapsed_time(b) for a, b in ev)[4]
-    assert int((first != H).sum().item()) == 0
+    def timed(p):
+        def go():
+            sw.kernels.safe_rollouts(p, p_sim, H, pol, sw._lib.COST_MAX_ABS_THETADOT, 0, 1e9, 1e9, traj=traj,
+                                     first_refused=first)
+        for _ in range(3):
+            go()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+        for a, b in ev:
+            a.record()
+            go()
+            b.record()
+        torch.cuda.synchronize()
+        assert int((first != H).sum().item()) == 0
+        return sorted(a.elapsed_time(b) for a, b in ev)[4]
+    ms = timed(p_real)                                      # n = 3, <= 8192 rollouts: the mirror-quad form
+    ms_lane = timed(sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3, flags=sw._lib.FLAG_ROLLOUT_LANE))
     out = {"rollouts": n_roll, "horizon": H, "fused_ms_per_launch": ms, "env_steps_per_s": n_roll * H / (ms * 1e-3),
            "physics_steps_per_s": 2 * n_roll * H / (ms * 1e-3),
-           "kernel": f"safe_rollout_kernel<{n}> (one rollout per lane, trajectory captured)"}
+           "kernel": ("safe_rollout_oct3_kernel<true,false> (two mirror quads per rollout: one geometry, two dynamics "
+                      "per env-step, 170 instructions)" if n == 3 else f"safe_rollout_kernel<{n}>"),
+           "lane_form_ms_per_launch": ms_lane, "trajectory_capture": True}
     real = sw.SwimmerEnv(n=n, l_i=0.8, m_i=1.2, k=10.2, device=device)
     agent = sw.safe_ars.Safe_ARS(sw.safe_ars.MaxAbsThetaDot(), 1e9, 1e9, sw.SwimmerEnv(n=n, device=device))
     P = pol.cpu().numpy()
