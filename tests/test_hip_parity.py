@@ -1037,3 +1037,29 @@ def test_top_b_selection_with_ties_at_every_size(sw, n_dir):
                               alpha=0.01, b=float(n_dir), top_b=top_b, sigma_out=sig)
         assert abs(float(sig) - sigma) <= 1e-13 * sigma, (n_dir, top_b)
         assert np.abs(pol.cpu().numpy() - 0.01 * grad).max() <= 1e-12 * max(1.0, np.abs(grad).max()), (n_dir, top_b)
+
+
+def test_the_two_gate_kernel_forms_agree_at_size(sw):
+    """2048 random gated rollouts (n = 3, H = 300, policy gains 0.05 ... 3): the mirror-quad form and the one-rollout-
+    per-lane form of sw_safe_rollouts_f64 must close the gate at the same step for every rollout, count the same
+    violations and produce the same states (they compute the look-ahead with different arithmetic: ~1e-16 apart, a
+    threshold would have to be hit to that precision for the decisions to differ)."""
+    rs = np.random.RandomState(99)
+    R, H, m, d = 2048, 300, 2, 8
+    pol = torch.as_tensor(rs.uniform(0.05, 3.0, R)[:, None, None] * (2 * rs.rand(R, m, d) - 1), device="cuda:0")
+    p_sim = sw.SwParams.make(3)
+    out = {}
+    for form, flags in (("quad", 0), ("lane", sw._lib.FLAG_ROLLOUT_LANE)):
+        p_real = sw.SwParams.make(3, 0.8, 1.2, 10.2, 1e-3, flags=flags)
+        traj = torch.empty((H, d, R), dtype=torch.float64, device="cuda:0")
+        first = torch.empty(R, dtype=torch.int32, device="cuda:0")
+        viol = torch.empty(R, dtype=torch.int32, device="cuda:0")
+        ret = sw.kernels.safe_rollouts(p_real, p_sim, H, pol, sw._lib.COST_MAX_ABS_THETADOT, 0, 0.6, 0.55, traj=traj,
+                                       first_refused=first, violations=viol)
+        out[form] = (ret.cpu().numpy(), traj.cpu().numpy(), first.cpu().numpy(), viol.cpu().numpy())
+    fq, fl = out["quad"][2], out["lane"][2]
+    assert np.array_equal(fq, fl)
+    assert 0 < (fq < H).sum() < R and len(np.unique(fq)) > 50          # refused early, late and never
+    assert np.array_equal(out["quad"][3], out["lane"][3]) and out["quad"][3].sum() > 0
+    assert np.abs(out["quad"][1] - out["lane"][1]).max() <= 1e-9
+    assert np.abs(out["quad"][0] - out["lane"][0]).max() <= 1e-9 * max(1.0, np.abs(out["lane"][0]).max())
