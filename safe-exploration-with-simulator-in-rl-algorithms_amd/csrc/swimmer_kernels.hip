@@ -1592,7 +1592,8 @@ rollout_oct3_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__res
 // and the real step: per step one geometry, two `oct3_dynamics` (simulator constants on copies of Gdot / thetadot,
 // real constants), the cost of the simulated next state on the lanes that own the observed quantity, one AND over
 // the rollout's eight lanes (three DPP-ANDs: the two mirror quads differ by rounding, the decision must not), and
-// the real step committed through selects.  ~190 instructions per env-step instead of ~640 in the lane form.
+// the real step committed through selects.  170 instructions per env-step (186 with the violation count) instead of
+// ~640 in the lane form: 0.354 ms per 1024 gated rollouts x 1000 steps against 1.13 ms (profiles/r04_z).
 // A refused rollout keeps recomputing the same refused step (its state no longer changes), as in the reference.
 __device__ __forceinline__ double oct_sel(bool take, double a, double b) { return take ? a : b; }
 
