@@ -1967,6 +1967,172 @@ rollout_row_kernel(sw::Consts C, int64_t n_roll, int32_t H, const double *__rest
 }
 
 // ------------------------------------------------------------------------------------
+// The safe-exploration gate for n = 4..8 in the ROW form of rollout_row_kernel (one segment per lane, one rollout per
+// 16-lane DPP row): per env-step two `row_step`s -- the simulator's look-ahead on copies of the state with the
+// simulator's constants and policy scaling, then the real step on copies, committed through selects where the gate
+// is open.  Gdot is replicated bit-identically on the row's lanes and lane i + 8 mirrors lane i bit for bit, so every
+// lane of a row computes the SAME cost from broadcasts and the decision needs no vote.  ~2 x 239 instructions per
+// env-step at n = 6 instead of ~2 x 1054 in the lane form.  Range checks per trip as in rollout_row_kernel (a refused
+// rollout's angles do not move at all, so the trip's travel bound holds a fortiori).
+template <int N>
+__global__ void __launch_bounds__(kRowBlock)
+safe_rollout_row_kernel(sw::Consts Cr, sw::Consts Cs, int64_t n_roll, int32_t H,
+                        const double *__restrict__ policies, int32_t cost_kind, int32_t cost_index,
+                        double sim_thresh, double real_thresh, int32_t want_violations,
+                        double *__restrict__ returns, double *__restrict__ traj, int32_t has_traj,
+                        int32_t *__restrict__ first_refused, int32_t *__restrict__ violations,
+                        int32_t *__restrict__ status)
+{
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int D = 2 * N + 2, M = N - 1;
+    const int tid = threadIdx.x;
+    const int q = tid & 15;
+    const bool owner = q < N;
+    const bool cosine = q >= 8;
+    const int seg = ((q & 7) < N) ? (q & 7) : 0;
+    const int64_t r_raw = (int64_t)blockIdx.x * kMomGroup + (tid >> 4);
+    const bool valid = r_raw < n_roll;
+    const int64_t r = valid ? r_raw : n_roll - 1;
+    const sw::RowLane<N> Lr = sw::row_lane<N>(Cr, seg), Ls = sw::row_lane<N>(Cs, seg);
+    const int cth = 2 + 2 * seg, cthd = 3 + 2 * seg;
+    double V[D], Vs[D], nbias, nbias_s;       // the policy rows scaled with each model's 12 / (m l^2)
+    {
+        int cols[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) cols[j] = j;
+        load_policy_row<D, M, false>(policies + r * (M * D), nullptr, 1.0, 0.0, nullptr, nullptr, Cr.c12, seg, cols,
+                                     V, nbias);
+        load_policy_row<D, M, false>(policies + r * (M * D), nullptr, 1.0, 0.0, nullptr, nullptr, Cs.c12, seg, cols,
+                                     Vs, nbias_s);
+    }
+    double gdx = 0.0, gdy = 0.0, th = kHalfPi, thd = 0.0;      // real_env.reset() (:133)
+    const uint32_t slab = (uint32_t)(D * n_roll * 8);
+    const uint32_t kDrop = 0xfffffff0u;
+    const uint32_t off_th = (owner && valid) ? (uint32_t)(((int64_t)cth * n_roll + r) * 8) : kDrop;
+    const uint32_t off_thd = (owner && valid) ? (uint32_t)(((int64_t)cthd * n_roll + r) * 8) : kDrop;
+    const uint32_t off_gx = (q == 0 && valid) ? (uint32_t)(r * 8) : kDrop;
+    const uint32_t off_gy = (q == 1 && valid) ? (uint32_t)((n_roll + r) * 8) : kDrop;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        traj, 0, has_traj ? (int)(uint32_t)((int64_t)H * slab) : 0, 0x00020000);
+    uint32_t soff = 0;
+    auto store_cell = [&](double v, uint32_t voff) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        union { double d; v2i i; } u;
+        u.d = v;
+        __builtin_amdgcn_raw_buffer_store_b64(u.i, trs, (int)voff, (int)soff, SW_TRAJ_STORE_AUX);
+    };
+    double thmax = 0.0, rq_last = 1.0, ret_x = 0.0, ret_y = 0.0;
+    int32_t taken = 0, over = 0;
+    bool alive = true;
+    const int designation = cosine ? 1 : 0;
+    sw::OctTrig A;
+    A.r = th;
+    A.kd = 0.0;
+    sw::oct3_renorm(A, designation, thmax);
+    // cost(obs) of a state held in row form: every lane of the row gets the same value (broadcasts of bit-identical
+    // copies); index decoded once: which segment lane owns it, and whether it is theta or thetadot
+    const int cseg = (cost_index >= 2) ? ((cost_index - 2) >> 1) : 0;
+    const bool c_thd = cost_index >= 2 && ((cost_index - 2) & 1);
+    auto cost_of = [&](double gx, double gy, double th_, double thd_) -> double {
+        if (cost_kind == SW_COST_MAX_ABS_THETADOT) {
+            double all[N];
+            sw::RowGather<N>::run(thd_, all);
+            double c = fabs(all[0]);
+            bool nan = all[0] != all[0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) {
+                c = fmax(c, fabs(all[k]));
+                nan = nan || (all[k] != all[k]);
+            }
+            return nan ? __builtin_nan("") : c;
+        }
+        if (cost_index == 0) return fabs(gx);
+        if (cost_index == 1) return fabs(gy);
+        double all[N];
+        sw::RowGather<N>::run(c_thd ? thd_ : th_, all);
+        double v = all[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) v = (cseg == k) ? all[k] : v;
+        return fabs(v);
+    };
+    auto one_step = [&](auto slow) {
+        // the simulator's look-ahead from the real state (:120-121), on copies
+        double sgx = gdx, sgy = gdy, sth = th, sthd = thd, smax = 0.0;
+        sw::OctTrig As = A;
+        (void)sw::row_step<N, decltype(slow)::value>(Cs, Ls, Vs, nbias_s, cosine, designation, sgx, sgy, As, sth, sthd,
+                                                     smax);
+        const bool safe = (cost_of(sgx, sgy, sth, sthd) <= sim_thresh) && alive;      // :122, NaN refuses
+        alive = safe;
+        // the real step on copies, committed where the gate is open (:142)
+        double rgx = gdx, rgy = gdy, rth = th, rthd = thd, rmax = thmax;
+        sw::OctTrig Ar = A;
+        const double rq = sw::row_step<N, decltype(slow)::value>(Cr, Lr, V, nbias, cosine, designation, rgx, rgy, Ar, rth,
+                                                                 rthd, rmax);
+        gdx = safe ? rgx : gdx;
+        gdy = safe ? rgy : gdy;
+        th = safe ? rth : th;
+        thd = safe ? rthd : thd;
+        A.r = safe ? Ar.r : A.r;
+        if (decltype(slow)::value) {      // the checked loop re-normalises inside the step: take all of it
+            A.kd = safe ? Ar.kd : A.kd;
+            A.selS = safe ? Ar.selS : A.selS;
+            A.selC = safe ? Ar.selC : A.selC;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) A.k[k] = safe ? Ar.k[k] : A.k[k];
+            thmax = safe ? rmax : thmax;
+        }
+        rq_last = safe ? rq : rq_last;
+        ret_x += safe ? gdx : 0.0;
+        ret_y += safe ? gdy : 0.0;
+        taken += safe ? 1 : 0;
+        if (want_violations) over += (safe && (cost_of(gdx, gdy, th, thd) > real_thresh)) ? 1 : 0;   // :143
+        store_cell(th, off_th);
+        store_cell(thd, off_thd);
+        store_cell(gdx, off_gx);
+        store_cell(gdy, off_gy);
+        soff += slab;
+    };
+    auto too_fast = [&]() -> bool { return __any((4.0 * Cr.h) * fabs(thd) > sw::kTripSlack); };
+    int32_t t = 0;
+    while (t < H) {
+        while (t < H) {                              // unchecked trips of (up to) four steps
+            if (__builtin_expect(too_fast(), 0)) break;
+            const double reach = __builtin_fma(4.0 * Cr.h, fabs(thd), fabs(A.r));
+            if (__builtin_expect(__any(reach > sw::kPio4), 0)) sw::oct3_renorm(A, designation, thmax);
+            const int32_t t_end = min(H, t + 4);
+#pragma unroll 1
+            for (; t < t_end; ++t) one_step(std::false_type{});
+        }
+#pragma unroll 1
+        for (; t < H && too_fast(); ++t) one_step(std::true_type{});
+    }
+    thmax = fmax(thmax, fabs(th));
+    {
+        double bad[N], big[N], piv[N];
+        const bool fin = isfinite(th) && isfinite(thd) && isfinite(gdx) && isfinite(gdy);
+        sw::RowGather<N>::run(fin ? 0.0 : 1.0, bad);
+        sw::RowGather<N>::run(thmax, big);
+        sw::RowGather<N>::run(rq_last, piv);
+        double nbad = 0.0, tmax = 0.0, pmin = 1.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            nbad += bad[k];
+            tmax = fmax(tmax, big[k]);
+            pmin = fmin(pmin, piv[k]);
+        }
+        const int code = ((pmin > 0.0) ? 0 : SW_STATUS_SINGULAR) | ((nbad == 0.0) ? 0 : SW_STATUS_NONFINITE) |
+                         ((tmax < sw::kAngleLimit) ? 0 : SW_STATUS_RANGE);
+        if (valid && q == 0) {
+            const double total = __builtin_fma(Cr.dirx, ret_x, Cr.diry * ret_y);
+            returns[r] = (code & SW_STATUS_RANGE) ? __builtin_nan("") : total;
+            if (first_refused) first_refused[r] = taken;
+            if (violations) violations[r] = over;
+            if (status) status[r] = code;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // two sums with one pair of barriers (the update kernel is pure latency: every barrier counts)
 template <int BLOCK>
 __device__ __forceinline__ void block_sum2(double &a, double &b, double (*sh2)[2])
@@ -2636,6 +2802,23 @@ int sw_safe_rollouts_f64(const sw_params *real, const sw_params *sim, int64_t n_
             if (violations) SW_LAUNCH_SAFE_OCT(false, true); else SW_LAUNCH_SAFE_OCT(false, false);
         }
 #undef SW_LAUNCH_SAFE_OCT
+        return launch_status();
+    }
+    if (use_row(real, n_roll, H, traj != nullptr)) {
+        // n = 4..8 while SIMDs are idle: the row form (two row_steps per env-step)
+        const unsigned rgrid = (unsigned)((n_roll + kMomGroup - 1) / kMomGroup);
+#define SW_LAUNCH_SAFE_ROW(NN_)                                                                                 \
+    hipLaunchKernelGGL((safe_rollout_row_kernel<NN_>), dim3(rgrid), dim3(kRowBlock), 0, (hipStream_t)stream, Cr, \
+                       Cs, n_roll, H, policies, cost_kind, cost_index, sim_thresh, real_thresh,                 \
+                       violations ? 1 : 0, returns, traj, traj ? 1 : 0, first_refused, violations, status)
+        switch (real->n) {
+        case 4: SW_LAUNCH_SAFE_ROW(4); break;
+        case 5: SW_LAUNCH_SAFE_ROW(5); break;
+        case 6: SW_LAUNCH_SAFE_ROW(6); break;
+        case 7: SW_LAUNCH_SAFE_ROW(7); break;
+        default: SW_LAUNCH_SAFE_ROW(8); break;
+        }
+#undef SW_LAUNCH_SAFE_ROW
         return launch_status();
     }
     const unsigned grid = (unsigned)((n_roll + kRollBlock - 1) / kRollBlock);
