@@ -1063,3 +1063,39 @@ def test_the_two_gate_kernel_forms_agree_at_size(sw):
     assert np.array_equal(out["quad"][3], out["lane"][3]) and out["quad"][3].sum() > 0
     assert np.abs(out["quad"][1] - out["lane"][1]).max() <= 1e-9
     assert np.abs(out["quad"][0] - out["lane"][0]).max() <= 1e-9 * max(1.0, np.abs(out["lane"][0]).max())
+
+
+@pytest.mark.parametrize("n", [4, 6, 8])
+def test_row_form_gate_with_fast_trips(sw, n):
+    """The row-form gate kernel (n = 4 ... 8) where angular velocities pass 10 rad/s -- its per-step-checked loop, in
+    which a committed step takes over the whole re-normalised angle state -- before the gate closes at 25 rad/s:
+    against the oracle's Safe_ARS restatement and against the lane form."""
+    from oracle import safe_ars_oracle as sao
+    rs = np.random.RandomState(500 + n)
+    d, m, H, R = 2 * n + 2, n - 1, 150, 48
+    pol = rs.uniform(2.0, 9.0, R)[:, None, None] * (2 * rs.rand(R, m, d) - 1)
+    p_real, p_sim = oracle.OracleParams.make(n, 0.8, 1.2, 10.2, 1e-3), oracle.OracleParams.make(n)
+    idx = 3 + 2 * (n // 2)                                       # |thetadot| of a middle segment
+    cost = lambda ob: abs(ob[idx])                               # noqa: E731
+    got = {}
+    for form, flags in (("row", 0), ("lane", sw._lib.FLAG_ROLLOUT_LANE)):
+        traj = torch.empty((H, d, R), dtype=torch.float64, device="cuda:0")
+        first = torch.empty(R, dtype=torch.int32, device="cuda:0")
+        status = torch.empty(R, dtype=torch.int32, device="cuda:0")
+        sw.kernels.safe_rollouts(sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3, flags=flags), sw.SwParams.make(n), H,
+                                 torch.as_tensor(pol, device="cuda:0"), sw._lib.COST_ABS_OBS, idx, 25.0, 24.0, traj=traj,
+                                 first_refused=first, status=status)
+        got[form] = (traj.permute(2, 0, 1).cpu().numpy(), first.cpu().numpy(), status.cpu().numpy())
+    assert np.array_equal(got["row"][1], got["lane"][1])
+    fast = 0
+    for r in range(R):
+        Ro, sto = sao.safe_rollout(p_real, p_sim, cost, 25.0, pol[r], H)
+        if not np.isfinite(sto).all() or np.abs(sto).max() > 1e4:
+            continue                                             # explicit Euler blew up (in the reference too)
+        same = np.all(sto[1:] == sto[:-1], axis=1)
+        f_ref = int(np.argmax(same)) + 1 if same.any() else H
+        assert int(got["row"][1][r]) == f_ref
+        scale = max(1.0, np.abs(sto).max())
+        assert np.abs(got["row"][0][r] - sto).max() <= 1e-8 * scale
+        fast += int(np.abs(sto[:, 3::2]).max() > 10.0)
+    assert fast >= 5                                             # the checked loop was really exercised
