@@ -549,7 +549,7 @@ def aux_next_rows(sw, torch, device, n=3, H=1000, directions=512):
     return out
 
 
-def aux_safe_gate(sw, torch, device, n=3, n_roll=1024, H=1000):
+def aux_safe_gate(sw, torch, device, n=3, n_roll=1024, H=1000, lock_step=True):
     """SURVEY 8(f-1), third consumer: the safe-exploration gate (safe_ars/ars.py:111-153) at the size of a BASELINE
     iteration -- 1024 rollouts x H = 1000, every real step preceded by a one-step simulator look-ahead and the cost
     max_i |thetadot_i| (safe_ars/experiment.py:45), thresholds out of reach so that no lane ever stops (the most work
@@ -583,8 +583,11 @@ def aux_safe_gate(sw, torch, device, n=3, n_roll=1024, H=1000):
     out = {"rollouts": n_roll, "horizon": H, "fused_ms_per_launch": ms, "env_steps_per_s": n_roll * H / (ms * 1e-3),
            "physics_steps_per_s": 2 * n_roll * H / (ms * 1e-3),
            "kernel": ("safe_rollout_oct3_kernel<true,false> (two mirror quads per rollout: one geometry, two dynamics "
-                      "per env-step, 170 instructions)" if n == 3 else f"safe_rollout_kernel<{n}>"),
+                      "per env-step, 170 instructions)" if n == 3 else
+                      f"safe_rollout_row_kernel<{n}> (one segment per lane: two row_steps per env-step)"),
            "lane_form_ms_per_launch": ms_lane, "trajectory_capture": True}
+    if not lock_step:
+        return out
     real = sw.SwimmerEnv(n=n, l_i=0.8, m_i=1.2, k=10.2, device=device)
     agent = sw.safe_ars.Safe_ARS(sw.safe_ars.MaxAbsThetaDot(), 1e9, 1e9, sw.SwimmerEnv(n=n, device=device))
     P = pol.cpu().numpy()
@@ -867,6 +870,7 @@ def summary(line, aux):
         "estI_us": r3(dig(aux, "next_rows", "estimator_objective", "us_per_evaluation")),
         "gate_ms": r3(dig(aux, "next_rows", "safe_ars_gate", "fused_ms_per_launch")),
         "gate_sps": r3(dig(aux, "next_rows", "safe_ars_gate", "env_steps_per_s")),
+        "gate_n6_ms": r3(dig(aux, "next_rows", "safe_ars_gate_n6", "fused_ms_per_launch")),
         "v1_ms": r3(dig(aux, "next_rows", "ars_v1_iteration", "ms_per_iteration")),
         "topb_ms": r3(dig(aux, "next_rows", "ars_top_b_64_iteration", "ms_per_iteration")),
         "cpu_sps": r3(dig(line, "cpu_baseline", "value")), "cpu_cores": dig(line, "cpu_baseline", "cores"),
@@ -1059,6 +1063,8 @@ def run_rank(args):
             aux["next_rows"] = guarded(aux_next_rows, sw, torch, device)
             if isinstance(aux["next_rows"], dict):
                 aux["next_rows"]["safe_ars_gate"] = guarded(aux_safe_gate, sw, torch, device)
+                aux["next_rows"]["safe_ars_gate_n6"] = guarded(aux_safe_gate, sw, torch, device, n=6, n_roll=512,
+                                                               lock_step=False)
             aux["rollout_saturated"] = guarded(aux_rollout_saturated, sw, torch, device)
             # one wave per SIMD (65 536 rollouts, a 4.2 GB buffer): the same kernel streams faster
             # than with four (16.8 GB, a 2 MB stride between the rows a step writes)
