@@ -144,7 +144,9 @@ int sw_rollout_f64(const sw_params *p, int64_t n_roll, int32_t H, const double *
  * the parameters `sim` from the real state under the proposed action policy @ obs (:139), and
  * cost(simulated observation) <= sim_thresh.  A refused step leaves the state where it is (:150-151; the rollout
  * then stays refused: it proposes the same action again).  `real` and `sim` must have the same number of segments;
- * the model flag of `real` / `sim` is ignored (Gym model).  The whole loop is ONE launch, one rollout per lane.
+ * the model flag of `real` / `sim` is ignored (Gym model).  The whole loop is ONE launch: n = 3 up to 8192 rollouts in the
+ * mirror-quad form (the look-ahead and the real step share the step's geometry), n = 4..8 in the row form while SIMDs are
+ * idle, one rollout per lane otherwise (or with SW_FLAG_ROLLOUT_LANE in real->flags); same results to rounding.
  *   policies      : [n_roll][m][d]
  *   cost_kind     : SW_COST_ABS_OBS            cost = |obs[cost_index]|, obs = [Gdx, Gdy, th_1, thd_1, ...]
  *                   SW_COST_MAX_ABS_THETADOT   cost = max_i |thetadot_i|  (safe_ars/experiment.py:45; cost_index unused)
