@@ -1085,6 +1085,13 @@ def test_row_form_gate_with_fast_trips(sw, n):
         sw.kernels.safe_rollouts(sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3, flags=flags), sw.SwParams.make(n), H,
                                  torch.as_tensor(pol, device="cuda:0"), sw._lib.COST_ABS_OBS, idx, 25.0, 24.0, traj=traj,
                                  first_refused=first, status=status)
+        ret = sw.kernels.safe_rollouts(sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3, flags=flags), sw.SwParams.make(n), H,
+                                       torch.as_tensor(pol, device="cuda:0"), sw._lib.COST_ABS_OBS, idx, 25.0, 24.0,
+                                       traj=traj, first_refused=first)
+        # without any optional output (no trajectory buffer, no bookkeeping arrays): the same returns, bit for bit
+        bare = sw.kernels.safe_rollouts(sw.SwParams.make(n, 0.8, 1.2, 10.2, 1e-3, flags=flags), sw.SwParams.make(n), H,
+                                        torch.as_tensor(pol, device="cuda:0"), sw._lib.COST_ABS_OBS, idx, 25.0, 24.0)
+        assert torch.equal(ret.nan_to_num(nan=-7.0), bare.nan_to_num(nan=-7.0))
         got[form] = (traj.permute(2, 0, 1).cpu().numpy(), first.cpu().numpy(), status.cpu().numpy())
     assert np.array_equal(got["row"][1], got["lane"][1])
     fast = 0
